@@ -1,0 +1,345 @@
+"""Pins the CPU oracle (oracle/rt_oracle.cpp) against every known-answer test
+the reference holds for the render path.  Each test names
+the reference test it restates (file:line under /root/reference/)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+L = O.lib()
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def v(*x):
+    return np.array(x, dtype=np.float64)
+
+
+EMISSIVE = dict(type="Emissive", color=[1.0, 0.0, 0.0])
+CAM = dict(eye=[0, 0, 0], look_at=[0, 0, -1], up=[0, 1, 0], fovy=45)
+
+
+def empty_scene():
+    return O.OracleScene(10, 10, [0, 0, 0], CAM)
+
+
+# ---- src/math/vec3.rs:256-346 ------------------------------------------------
+def test_dot():  # vec3.rs:257-269
+    d, c = C.c_double(), np.zeros(3)
+    L.orc_vec_dot_cross(p(v(0, 0, 0)), p(v(1, 1, 1)), C.byref(d), p(c))
+    assert d.value == 0.0
+    L.orc_vec_dot_cross(p(v(1, 1, 1)), p(v(2, 3, 4)), C.byref(d), p(c))
+    assert d.value == 9.0
+
+
+def test_cross():  # vec3.rs:272-290
+    d, c = C.c_double(), np.zeros(3)
+    L.orc_vec_dot_cross(p(v(1, 0, 0)), p(v(0, 1, 0)), C.byref(d), p(c))
+    assert list(c) == [0.0, 0.0, 1.0]
+    L.orc_vec_dot_cross(p(v(1, 0, 0)), p(v(1, 0, 0)), C.byref(d), p(c))
+    assert list(c) == [0.0, 0.0, 0.0]
+
+
+def test_normalized_length():  # vec3.rs:293-310
+    out = np.zeros(3)
+    L.orc_vec_normalized(p(v(1, 2, 2)), p(out))
+    assert list(out) == [1.0 / 3.0, 2.0 / 3.0, 2.0 / 3.0]
+    L.orc_vec_normalized(p(v(0, 0, 0)), p(out))
+    assert list(out) == [0.0, 0.0, 0.0]
+
+
+def test_near_zero():  # vec3.rs:331-337
+    assert L.orc_vec_near_zero(p(v(1e-13, 1e-13, 1e-13))) == 1
+    assert L.orc_vec_near_zero(p(v(1e-5, 1e-5, 1e-5))) == 0
+
+
+def test_random_unit_vector():  # vec3.rs:340-346
+    out = np.zeros(3)
+    for seed in range(200):
+        L.orc_random_unit_vector(seed, p(out))
+        n = np.linalg.norm(out)
+        assert 9e-6 <= n <= 1.0 + 1e-6
+        L.orc_random_in_unit_sphere(seed, p(out))
+        assert out @ out < 1.0
+
+
+def test_reflect():  # vec3.rs:129-131 (formula)
+    out = np.zeros(3)
+    L.orc_vec_reflect(p(v(1, -1, 0)), p(v(0, 1, 0)), p(out))
+    assert list(out) == [1.0, 1.0, 0.0]
+
+
+# ---- src/raytracer/anti_aliasing.rs:126-294 ----------------------------------
+def ssaa_parse(s):
+    kind, res = C.c_int(-1), C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    rc = L.orc_ssaa_parse(s.encode(), C.byref(kind), C.byref(res), err, 256)
+    return rc, kind.value, res.value, err.value.decode()
+
+
+def ssaa_sample(kind, N, x, y, seed=7):
+    out = np.zeros((N * N, 2))
+    L.orc_ssaa_sample(kind, N, x, y, seed, p(out))
+    return out
+
+
+def test_grid_sampling_single():  # anti_aliasing.rs:131-145
+    s = ssaa_sample(0, 1, 0, 0)
+    assert len(s) == 1 and tuple(s[0]) == (0.0, 0.0)
+
+
+def test_grid_sampling_multiple():  # anti_aliasing.rs:148-180
+    s = ssaa_sample(0, 2, 0, 0)
+    assert [tuple(r) for r in s] == [(0.0, 0.0), (0.0, 0.5), (0.5, 0.0), (0.5, 0.5)]
+
+
+def test_jitter_sampling():  # anti_aliasing.rs:183-215
+    for seed in range(50):
+        s = ssaa_sample(1, 2, 0, 0, seed)
+        assert len(s) == 4
+        assert 0.0 <= s[0][0] <= 0.5 and 0.0 <= s[0][1] <= 0.5
+        assert 0.0 <= s[1][0] <= 0.5 and 0.5 <= s[1][1] <= 1.0
+        assert 0.5 <= s[2][0] <= 1.0 and 0.0 <= s[2][1] <= 0.5
+        assert 0.5 <= s[3][0] <= 1.0 and 0.5 <= s[3][1] <= 1.0
+
+
+def test_ssaa_uniform_from_str():  # anti_aliasing.rs:218-249
+    rc, kind, res, _ = ssaa_parse("uniform:2")
+    assert rc == 0 and res == 2
+    assert kind == 1  # the reference maps "uniform" to Jitter (anti_aliasing.rs:75)
+    assert len(ssaa_sample(kind, res, 0, 0)) == 4
+    rc, _, _, err = ssaa_parse("uniform")
+    assert rc != 0 and err == "no arguments supplied, need resolution for uniform"
+    rc, _, _, err = ssaa_parse("uniform:invalid")
+    assert rc != 0 and err == "resolution has to be an integer"
+
+
+def test_ssaa_jitter_from_str():  # anti_aliasing.rs:252-283
+    rc, kind, res, _ = ssaa_parse("jitter:2")
+    assert rc == 0 and kind == 1 and res == 2
+    rc, _, _, err = ssaa_parse("jitter")
+    assert rc != 0 and err == "no arguments supplied, need resolution for jitter"
+    rc, _, _, err = ssaa_parse("jitter:invalid")
+    assert rc != 0 and err == "resolution has to be an integer"
+
+
+def test_ssaa_invalid_method_from_str():  # anti_aliasing.rs:286-293
+    rc, _, _, err = ssaa_parse("invalid")
+    assert rc != 0 and err == "unknown method"
+
+
+# ---- src/raytracer/scene/intersections.rs:253-400 ----------------------------
+def test_aabb_intersection():  # intersections.rs:271-278
+    o, d = v(0, 0, 0), v(0, 1, 0)
+    assert L.orc_aabb_intersect(p(v(0, 2, 0)), p(v(1, 2, 1)), p(o), p(d)) == 1
+    assert L.orc_aabb_intersect(p(v(1, 0, 1)), p(v(2, 1, 2)), p(o), p(d)) == 0
+
+
+def test_aabb_intersection_inside():  # intersections.rs:281-286
+    assert L.orc_aabb_intersect(p(v(-1, -1, -1)), p(v(1, 1, 1)), p(v(0, 0, 0)), p(v(1, 0, 0))) == 1
+
+
+def test_mesh_intersection():  # intersections.rs:289-311
+    sc = empty_scene()
+    sc.add_mesh([[5, -1, -1], [5, 1, 0], [5, -1, 1]], [[0, 1, 2]], [0], [EMISSIVE])
+    # NB the reference test does not call compute_aabb(); prepare() does, the hit is inside the box anyway
+    sc.prepare()
+    h = sc.closest_hit([0, 0, 0], [1, 0, 0])
+    assert h is not None
+    assert list(h["point"]) == [5.0, 0.0, 0.0]
+    assert list(h["normal"]) == [1.0, 0.0, 0.0]
+    assert h["t"] == 5.0
+    assert (h["object_id"], h["triangle_id"]) == (0, 0)
+
+
+def test_mesh_intersection_negative():  # intersections.rs:314-327
+    sc = empty_scene()
+    sc.add_mesh([[5, 1, -1], [5, 1, 0], [5, 1, 1]], [[0, 1, 2]], [0], [EMISSIVE])
+    sc.prepare()
+    assert sc.closest_hit([0, 0, 0], [1, 0, 0]) is None
+
+
+def test_sphere_intersection():  # intersections.rs:330-350
+    sc = empty_scene()
+    sc.add_sphere([2, 0, 1], 1.0, EMISSIVE)
+    sc.prepare()
+    h = sc.closest_hit([0, 0, 0], [1, 0, 0])
+    assert list(h["point"]) == [2.0, 0.0, 0.0]
+    assert list(h["normal"]) == [0.0, 0.0, -1.0]
+    assert h["t"] == 2.0
+
+
+def test_sphere_intersection_negative():  # intersections.rs:353-363
+    sc = empty_scene()
+    sc.add_sphere([0, 1, 0], 0.5, EMISSIVE)
+    sc.prepare()
+    assert sc.closest_hit([0, 0, 0], [1, 0, 0]) is None
+
+
+def test_plane_intersection():  # intersections.rs:366-386
+    sc = empty_scene()
+    sc.add_plane([2, 0, 0], [-1, 0, 0], EMISSIVE)
+    sc.prepare()
+    h = sc.closest_hit([0, 0, 0], [1, 0, 0])
+    assert list(h["point"]) == [2.0, 0.0, 0.0]
+    assert list(h["normal"]) == [-1.0, 0.0, 0.0]
+    assert h["t"] == 2.0
+
+
+def test_plane_intersection_negative():  # intersections.rs:389-399
+    sc = empty_scene()
+    sc.add_plane([-1, 0, 0], [1, 0, 0], EMISSIVE)
+    sc.prepare()
+    assert sc.closest_hit([0, 0, 0], [1, 0, 0]) is None
+
+
+# ---- src/raytracer/scene/scene.rs:188-297 ------------------------------------
+def test_closest_intersection():  # scene.rs:206-241
+    sc = empty_scene()
+    m = dict(type="Emissive", color=[0, 0, 0])
+    sc.add_sphere([5, 0, 0], 1.0, m)
+    sc.add_sphere([5, 0, 0], 1.5, m)
+    sc.prepare()
+    h = sc.closest_hit([0, 0, 0], [1, 0, 0])
+    assert h["t"] == 3.5 and h["object_id"] == 1
+
+
+def _test_objects(sc, material):  # scene.rs:243-263
+    sc.add_sphere([0, 0, 0], 0.0, material)
+    sc.add_plane([0, 0, 0], [0, 0, 0], material)
+    sc.add_mesh([[3, 0, 0], [0, 3, 0], [0, 0, 3]], [[0, 1, 2]], [0], [material])
+
+
+def test_is_lights():  # scene.rs:266-279
+    sc = empty_scene()
+    _test_objects(sc, dict(type="Emissive", color=[0, 0, 0]))
+    sc.prepare()
+    assert len(sc.lights()) == 3
+    sc = empty_scene()
+    _test_objects(sc, dict(type="Lambertian", albedo=[0, 0, 0]))
+    sc.prepare()
+    assert len(sc.lights()) == 0
+
+
+def test_light_from_object():  # scene.rs:282-296
+    sc = empty_scene()
+    _test_objects(sc, dict(type="Emissive", color=[0, 0, 0]))
+    sc.prepare()
+    sphere, plane, mesh = sc.lights()
+    assert len(sphere) == 1 and list(sphere[0]) == [0.0, 0.0, 0.0]
+    assert len(plane) == 1 and list(plane[0]) == [0.0, 0.0, 0.0]
+    assert len(mesh) == 1 and list(mesh[0]) == [1.0, 1.0, 1.0]
+
+
+# ---- src/raytracer/scene/materials.rs:255-379 --------------------------------
+def test_refract():  # materials.rs:272-280
+    out = np.zeros(3)
+    L.orc_refract(p(v(1, 0, 0)), p(v(0, 1, 0)), 1.0, p(out))
+    assert list(out) == [1.0, 0.0, 0.0]
+
+
+def test_reflectance():  # materials.rs:283-287
+    assert L.orc_reflectance(0.0, 1.0) == 1.0
+
+
+def scatter(mtype, rgb, param, normal, seed=3):
+    d, c = np.zeros(3), np.zeros(3)
+    rc = L.orc_scatter(mtype, p(v(*rgb)), param, p(v(0, 0, 0)), p(v(0, 0, 0)), p(v(0, 0, 0)), p(v(*normal)), seed, p(d), p(c))
+    return rc, d, c
+
+
+def test_emissive_scatter():  # materials.rs:290-308
+    rc, _, c = scatter(4, (1.0, 0.5, 0.0), 0.0, (0, 0, 0))
+    assert rc == 1 and list(c) == [1.0, 0.5, 0.0]
+
+
+def test_lambertian_scatter():  # materials.rs:311-329
+    rc, _, c = scatter(0, (1.0, 0.5, 0.0), 0.0, (0, 0, 0))
+    assert rc == 2 and list(c) == [1.0, 0.5, 0.0]
+
+
+def test_metal_scatter():  # materials.rs:332-357
+    rc, _, _ = scatter(1, (1.0, 0.5, 0.0), 0.5, (0, 0, 0))
+    assert rc == 0
+    for seed in range(20):
+        rc, _, c = scatter(1, (1.0, 0.5, 0.0), 0.5, (0, 1, 0), seed)
+        if rc != 0:
+            assert rc == 2 and list(c) == [1.0, 0.5, 0.0]
+
+
+def test_dieletrics_scatter():  # materials.rs:360-378
+    rc, _, c = scatter(2, (1.0, 0.5, 0.0), 0.5, (0, 0, 0))
+    assert rc == 2 and list(c) == [1.0, 0.5, 0.0]
+
+
+# ---- src/raytracer/image.rs:37-51 --------------------------------------------
+def test_to_output():
+    out = np.zeros(3, np.uint8)
+    L.orc_to_output(p(v(np.sqrt(0.75), 1.0, 0.0)), p(out))
+    assert list(out) == [221, 255, 0]
+    L.orc_to_output(p(v(float("nan"), -1.0, 7.0)), p(out))
+    assert list(out) == [0, 0, 255]
+
+
+def test_texture_albedo_exact_and_bilinear():  # materials.rs:197-230, image.rs:45-51
+    tex = np.zeros((4, 4, 3), np.uint8)
+    tex[..., 0] = np.arange(16).reshape(4, 4) * 10
+    out = np.zeros(3)
+    # x = 4*0.25 = 1, y = 4 - 4*0.5 = 2: exact texel (row 2, col 1)
+    L.orc_texture_albedo(4, 4, p(tex), 0.25, 0.5, p(out))
+    assert out[0] == 90 / 255.999
+    # x = 1.5, y = 2.5: mean of texels (2,1),(2,2),(3,1),(3,2)
+    L.orc_texture_albedo(4, 4, p(tex), 0.375, 0.375, p(out))
+    assert abs(out[0] - (90 + 100 + 130 + 140) / 4 / 255.999) < 1e-15
+
+
+# ---- golden-image facts -----------------------------------------
+def _golden_facts(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def test_oracle_reproduces_deterministic_pixels_of_spheres_png(golden_dir):
+    """spheres.png: pixels that see the emissive plane directly are exactly 221
+    (= trunc(255.999*sqrt(0.75))) -- pins gamma, quantisation and row order."""
+    gold = _golden_facts(os.path.join(golden_dir, "scenes/spheres/spheres.png"))
+    sc = O.OracleScene.from_yaml(os.path.join(golden_dir, "scenes/spheres/spheres.yaml"), base_dir=golden_dir)
+    out = sc.render(mode="jitter", N=2, depth=5, seed=11)["rgb8"]
+    g221 = np.all(gold == 221, axis=2)
+    assert g221.sum() == 19945
+    o221 = np.all(out == 221, axis=2)
+    # same region up to anti-aliased silhouette pixels (golden spp is unknown)
+    iou = (g221 & o221).sum() / float((g221 | o221).sum())
+    assert iou > 0.9
+    assert g221[:100].sum() > 0.5 * g221.sum()  # the band is at the top: row order
+
+
+def test_oracle_reproduces_deterministic_pixels_of_cube_png(golden_dir):
+    gold = _golden_facts(os.path.join(golden_dir, "scenes/cube/cube.png"))
+    sc = O.OracleScene.from_yaml(os.path.join(golden_dir, "scenes/cube/cube.yaml"), base_dir=golden_dir)
+    out = sc.render(mode="jitter", N=2, depth=5, seed=5)["rgb8"]
+    g114 = np.all(gold == 114, axis=2)
+    assert g114.sum() == 80240
+    o114 = np.all(out == 114, axis=2)
+    # at depth 5 a ground pixel is 114 when all 4 samples bounce to the emissive
+    # plane; the golden (unknown, higher spp) has the same plateau value
+    both = (g114 & o114).sum()
+    assert both > 0.5 * g114.sum()
+
+
+def test_oracle_image_close_to_goldens(golden_dir):
+    """Loose visual parity with the two committed renders (settings unknown =>
+    parity unpinned beyond this)."""
+    for name, thresh in (("spheres", 25.0), ("cube", 20.0)):
+        gold = _golden_facts(os.path.join(golden_dir, "scenes/%s/%s.png" % (name, name))).astype(np.float64)
+        sc = O.OracleScene.from_yaml(os.path.join(golden_dir, "scenes/%s/%s.yaml" % (name, name)), base_dir=golden_dir)
+        out = sc.render(mode="jitter", N=4, depth=5, seed=3)["rgb8"].astype(np.float64)
+        mse = np.mean((gold - out) ** 2)
+        psnr = 10 * np.log10(255.0 ** 2 / mse)
+        print(name, "PSNR vs golden", psnr)
+        assert psnr > thresh
