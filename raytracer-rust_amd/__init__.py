@@ -1,0 +1,8 @@
+"""MI355X-native render path behind the scene / camera / sampling surface of
+bsati/raytracer-rust.  The compute path is the HIP library `librtamd.so`
+(C ABI: include/rtamd.h, include/rtamd_host.h); this package is the thin host
+mirror of the reference's interface plus torch plumbing (device memory, streams,
+torch.distributed).  There is no CPU fallback: importing works without a GPU,
+rendering fails loudly without the library or a gfx950 device."""
+from .lib import RtError, load_library, library_path  # noqa: F401
+from .api import (Context, RenderParams, SSAADecodeError, Scene, SuperSampling, compute_image)  # noqa: F401

@@ -1,0 +1,274 @@
+#include "bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace rtamd {
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 4;        // primitives per leaf (the leaf encoding allows 8)
+constexpr uint32_t kMedianDepth = 40;   // beyond this depth fall back to median splits (bounds the depth)
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<float>::infinity(); mx[k] = -std::numeric_limits<float>::infinity(); }
+    }
+    void grow(const float* lo, const float* hi) {
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], lo[k]); mx[k] = std::max(mx[k], hi[k]); }
+    }
+    void grow(const Box& b) { grow(b.mn, b.mx); }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct TmpNode {
+    Box box;
+    int32_t left = -1, right = -1;   // children (TmpNode indices) or -1 for a leaf
+    uint32_t first = 0, count = 0;   // range of `order`
+};
+
+struct Builder {
+    const std::vector<PrimBox>& prims;
+    std::vector<uint32_t>& order;
+    std::vector<float> cx, cy, cz;   // centroids
+    explicit Builder(const std::vector<PrimBox>& p, std::vector<uint32_t>& o) : prims(p), order(o) {
+        size_t n = p.size();
+        cx.resize(n); cy.resize(n); cz.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            cx[i] = 0.5f * (p[i].mn[0] + p[i].mx[0]);
+            cy[i] = 0.5f * (p[i].mn[1] + p[i].mx[1]);
+            cz[i] = 0.5f * (p[i].mn[2] + p[i].mx[2]);
+        }
+    }
+    float centroid(uint32_t prim, int axis) const { return axis == 0 ? cx[prim] : (axis == 1 ? cy[prim] : cz[prim]); }
+
+    // Splits [first, first+count) in place; returns the size of the left part (0 = make a leaf).
+    uint32_t split(uint32_t first, uint32_t count, uint32_t depth) {
+        if (count <= kMaxLeaf) return 0;
+        uint32_t* idx = order.data() + first;
+        Box cb; cb.reset();
+        for (uint32_t i = 0; i < count; ++i) { float c[3] = {cx[idx[i]], cy[idx[i]], cz[idx[i]]}; cb.grow(c, c); }
+        int best_axis = -1; int best_bin = -1; float best_cost = std::numeric_limits<float>::infinity();
+        if (depth < kMedianDepth) {
+            for (int axis = 0; axis < 3; ++axis) {
+                float lo = cb.mn[axis], hi = cb.mx[axis];
+                if (!(hi > lo)) continue;
+                float scale = (float)kBins / (hi - lo);
+                Box bb[kBins]; uint32_t bc[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+                for (uint32_t i = 0; i < count; ++i) {
+                    int b = (int)((centroid(idx[i], axis) - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bb[b].grow(prims[idx[i]].mn, prims[idx[i]].mx); bc[b]++;
+                }
+                float la[kBins]; uint32_t lc[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = 0; b < kBins - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.half_area(); lc[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bb[b]); c += bc[b];
+                    if (lc[b - 1] == 0 || c == 0) continue;
+                    float cost = la[b - 1] * (float)lc[b - 1] + acc.half_area() * (float)c;
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b - 1; }
+                }
+            }
+        }
+        uint32_t nl = 0;
+        if (best_axis >= 0) {
+            float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+            float scale = (float)kBins / (hi - lo);
+            int axis = best_axis, bin = best_bin;
+            uint32_t* mid = std::partition(idx, idx + count, [&](uint32_t p) {
+                int b = (int)((centroid(p, axis) - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= bin;
+            });
+            nl = (uint32_t)(mid - idx);
+        }
+        if (nl == 0 || nl == count) {
+            // median split along the widest centroid axis (also the depth-bounding fallback)
+            int axis = 0; float w = -1.f;
+            for (int k = 0; k < 3; ++k) { float e = cb.mx[k] - cb.mn[k]; if (e > w) { w = e; axis = k; } }
+            nl = count / 2;
+            std::nth_element(idx, idx + nl, idx + count, [&](uint32_t a, uint32_t b) {
+                float ca = centroid(a, axis), cbv = centroid(b, axis);
+                return ca < cbv || (ca == cbv && a < b);
+            });
+        }
+        return nl;
+    }
+
+    // Builds the subtree for a range into `nodes` (appending); returns its root index.
+    int32_t build_range(std::vector<TmpNode>& nodes, uint32_t first, uint32_t count, uint32_t depth) {
+        struct Item { int32_t node; uint32_t depth; };
+        int32_t root = (int32_t)nodes.size();
+        nodes.emplace_back();
+        nodes[root].first = first; nodes[root].count = count;
+        std::vector<Item> stack; stack.push_back({root, depth});
+        while (!stack.empty()) {
+            Item it = stack.back(); stack.pop_back();
+            uint32_t f = nodes[it.node].first, c = nodes[it.node].count;
+            Box b; b.reset();
+            for (uint32_t i = 0; i < c; ++i) b.grow(prims[order[f + i]].mn, prims[order[f + i]].mx);
+            nodes[it.node].box = b;
+            uint32_t nl = split(f, c, it.depth);
+            if (nl == 0) continue;
+            int32_t l = (int32_t)nodes.size(); nodes.emplace_back();
+            int32_t r = (int32_t)nodes.size(); nodes.emplace_back();
+            nodes[l].first = f; nodes[l].count = nl;
+            nodes[r].first = f + nl; nodes[r].count = c - nl;
+            nodes[it.node].left = l; nodes[it.node].right = r;
+            stack.push_back({l, it.depth + 1});
+            stack.push_back({r, it.depth + 1});
+        }
+        return root;
+    }
+};
+
+void set_child_box(GpuNode& g, int which, const Box& b) {
+    // pad by a few ulps of the largest coordinate magnitude / extent so that the f32 slab
+    // test never culls a primitive the exact test would reach
+    float m = 0.f;
+    for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
+    float e = 4e-6f * m + 1e-30f;
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = b.mn[k] - e; hi[k] = b.mx[k] + e; }
+    if (which == 0) { g.n0[0] = lo[0]; g.n0[1] = hi[0]; g.n0[2] = lo[1]; g.n0[3] = hi[1]; g.n2[0] = lo[2]; g.n2[1] = hi[2]; }
+    else { g.n1[0] = lo[0]; g.n1[1] = hi[0]; g.n1[2] = lo[1]; g.n1[3] = hi[1]; g.n2[2] = lo[2]; g.n2[3] = hi[2]; }
+}
+}  // namespace
+
+void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)boxes.size();
+    out.nodes.clear(); out.order.resize(n); out.max_depth = 0;
+    for (uint32_t i = 0; i < n; ++i) out.order[i] = i;
+    if (n == 0) { out.build_ms = 0; return; }
+
+    Builder B(boxes, out.order);
+    std::vector<TmpNode> tmp;
+    if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+
+    if (n < 65536 || threads == 1) {
+        tmp.reserve(2 * (size_t)n / 2 + 16);
+        B.build_range(tmp, 0, n, 0);
+    } else {
+        // split the top of the tree serially until there are enough subtrees, then build those in parallel
+        struct Job { int32_t node; uint32_t depth; };
+        tmp.emplace_back(); tmp[0].first = 0; tmp[0].count = n;
+        std::vector<Job> frontier{{0, 0}};
+        while ((int)frontier.size() < threads * 4) {
+            size_t bi = 0;   // split the largest frontier range next
+            for (size_t i = 1; i < frontier.size(); ++i) if (tmp[frontier[i].node].count > tmp[frontier[bi].node].count) bi = i;
+            Job j = frontier[bi];
+            uint32_t f = tmp[j.node].first, c = tmp[j.node].count;
+            if (c <= 4096) break;
+            uint32_t nl = B.split(f, c, j.depth);
+            if (nl == 0) break;
+            int32_t l = (int32_t)tmp.size(); tmp.emplace_back();
+            int32_t r = (int32_t)tmp.size(); tmp.emplace_back();
+            tmp[l].first = f; tmp[l].count = nl; tmp[r].first = f + nl; tmp[r].count = c - nl;
+            tmp[j.node].left = l; tmp[j.node].right = r;
+            frontier[bi] = {l, j.depth + 1};
+            frontier.push_back({r, j.depth + 1});
+        }
+        std::vector<std::vector<TmpNode>> sub(frontier.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= frontier.size()) break;
+                B.build_range(sub[i], tmp[frontier[i].node].first, tmp[frontier[i].node].count, frontier[i].depth);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (int t = 0; t < threads; ++t) ts.emplace_back(work);
+        for (auto& t : ts) t.join();
+        // splice the subtrees in: sub[i][0] replaces the frontier node, the rest is appended
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            int32_t base = (int32_t)tmp.size();
+            auto fix = [&](int32_t c) { return c < 0 ? c : (c == 0 ? frontier[i].node : base + c - 1); };
+            TmpNode rootn = sub[i][0];
+            rootn.left = fix(rootn.left); rootn.right = fix(rootn.right);
+            tmp[frontier[i].node] = rootn;
+            for (size_t k = 1; k < sub[i].size(); ++k) {
+                TmpNode t = sub[i][k];
+                t.left = fix(t.left); t.right = fix(t.right);
+                tmp.push_back(t);
+            }
+        }
+        // boxes of the serially split top nodes (children first: process in reverse creation order)
+        std::vector<int32_t> top;
+        {
+            std::vector<int32_t> st{0};
+            std::vector<char> is_frontier(tmp.size(), 0);
+            for (auto& j : frontier) is_frontier[j.node] = 1;
+            while (!st.empty()) {
+                int32_t x = st.back(); st.pop_back();
+                if (is_frontier[x] || tmp[x].left < 0) continue;
+                top.push_back(x); st.push_back(tmp[x].left); st.push_back(tmp[x].right);
+            }
+        }
+        for (size_t k = top.size(); k-- > 0;) {
+            TmpNode& t = tmp[top[k]];
+            t.box = tmp[t.left].box; t.box.grow(tmp[t.right].box);
+        }
+    }
+
+    // flatten: one GpuNode per inner TmpNode, depth-first so that siblings' subtrees are contiguous
+    std::vector<int32_t> gpu_index(tmp.size(), -1);
+    struct Item { int32_t node; uint32_t depth; };
+    std::vector<Item> st;
+    auto leaf_code = [&](const TmpNode& t) { return ~(int32_t)((t.first << 3) | (t.count - 1)); };
+    if (tmp[0].left < 0) {
+        // single leaf: synthesise a root over two half leaves (n == 1: the same leaf twice,
+        // which is harmless because a tie with the same scan rank never replaces the hit)
+        GpuNode g; std::memset(&g, 0, sizeof(g));
+        const TmpNode& t = tmp[0];
+        uint32_t h = t.count >= 2 ? t.count / 2 : t.count;
+        TmpNode a = t, b = t;
+        a.count = h;
+        if (t.count >= 2) { b.first = t.first + h; b.count = t.count - h; }
+        a.box.reset(); b.box.reset();
+        for (uint32_t i = 0; i < a.count; ++i) a.box.grow(boxes[out.order[a.first + i]].mn, boxes[out.order[a.first + i]].mx);
+        for (uint32_t i = 0; i < b.count; ++i) b.box.grow(boxes[out.order[b.first + i]].mn, boxes[out.order[b.first + i]].mx);
+        set_child_box(g, 0, a.box); g.child0 = leaf_code(a);
+        set_child_box(g, 1, b.box); g.child1 = leaf_code(b);
+        out.nodes.push_back(g); out.max_depth = 1;
+    } else {
+        st.push_back({0, 1});
+        // first pass assigns indices in DFS order
+        std::vector<int32_t> dfs;
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            gpu_index[it.node] = (int32_t)dfs.size(); dfs.push_back(it.node);
+            out.max_depth = std::max(out.max_depth, it.depth);
+            const TmpNode& t = tmp[it.node];
+            if (tmp[t.right].left >= 0) st.push_back({t.right, it.depth + 1});
+            if (tmp[t.left].left >= 0) st.push_back({t.left, it.depth + 1});
+        }
+        out.nodes.resize(dfs.size());
+        for (size_t k = 0; k < dfs.size(); ++k) {
+            const TmpNode& t = tmp[dfs[k]];
+            GpuNode g; std::memset(&g, 0, sizeof(g));
+            const TmpNode& l = tmp[t.left]; const TmpNode& r = tmp[t.right];
+            set_child_box(g, 0, l.box); set_child_box(g, 1, r.box);
+            g.child0 = l.left >= 0 ? gpu_index[t.left] : leaf_code(l);
+            g.child1 = r.left >= 0 ? gpu_index[t.right] : leaf_code(r);
+            out.nodes[k] = g;
+        }
+    }
+    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace rtamd

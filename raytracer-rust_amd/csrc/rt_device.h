@@ -1,0 +1,77 @@
+// Device-side data layout shared by the kernels (rt_kernels.hip) and the C-ABI
+// host code (rt_api.hip).  Everything is written for gfx950 (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtamd {
+
+constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;    // hit code: nothing hit
+constexpr uint32_t HIT_PLANE_BIT = 0x80000000u;  // hit code: plane index in the low bits
+constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primitive
+constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
+
+// control block (uint32 words, zeroed at the start of every pass)
+constexpr int CTL_MAX_IT = 320;               // == RT_MAX_ITERATIONS
+constexpr int CTL_QCOUNT = 0;                 // [it]   rays in the queue consumed by iteration `it`
+constexpr int CTL_FETCH = CTL_MAX_IT + 8;     // [it]   dynamic-fetch cursor of the closest-hit kernel
+constexpr int CTL_OVERFLOW = 2 * (CTL_MAX_IT + 8);
+constexpr int CTL_NODES_LO = CTL_OVERFLOW + 1;   // 64-bit counters as two words (lo, hi)
+constexpr int CTL_PRIMS_LO = CTL_OVERFLOW + 3;
+constexpr int CTL_WORDS = CTL_OVERFLOW + 8;
+
+// Ray queue, structure of arrays of 16-byte words so that every wave-level access
+// is one contiguous 1 KiB transaction:
+//   a = (o.x, o.y, o.z, d.x)
+//   b = (d.y, d.z, bits(src prim code), bits(path id))      -- a,b: all the closest-hit kernel reads
+//   c = (throughput.r, .g, .b, bits(rng state))
+struct RayQueue {
+    float4* a;
+    float4* b;
+    float4* c;
+};
+
+// Primitive record, 48 bytes = 3 x float4, stored in BVH leaf order.
+//   triangle: r0 = (A.x, A.y, A.z, e1.x) r1 = (e1.y, e1.z, e2.x, e2.y) r2 = (e2.z, bits(gid), bits(PRIM_TRIANGLE), 0)
+//             e1 = B - A, e2 = C - A  (the reference's ab / ac, intersections.rs:153-154)
+//   sphere:   r0,r1 = 4 doubles (c.x, c.y, c.z, radius)                r2 = (0, bits(gid), bits(PRIM_SPHERE), 0)
+// gid = rank of the primitive in the reference's scan order (object index, then triangle
+// index): the tie-break key of scene.rs:43 / intersections.rs:170.
+//
+// meta (int4 per primitive, leaf order): (object index, triangle index or -1, material, uv offset or -1)
+struct DevScene {
+    const float4* nodes;      // 4 x float4 per node (bvh.h)
+    const float4* prims;      // 3 x float4 per primitive
+    const int4* meta;
+    const float* uvs;         // 6 floats per primitive that has uv: (u0,v0,u1,v1,u2,v2)
+    uint32_t n_prims;
+    uint32_t n_nodes;
+    const float4* planes;     // 2 x float4 per plane: (c.xyz, bits(gid)), (n.xyz, bits(material))
+    const int32_t* plane_object;
+    uint32_t n_planes;
+    const float4* materials;  // 2 x float4 per material: (r,g,b,param), bits(type, texture, 0, 0)
+    const int4* textures;     // (texel offset, width, height, 0)
+    const uchar4* texels;
+    const float4* lights;     // xyz of sample_points[0]
+    uint32_t n_lights;
+    float bg[3];
+    float eye[3], lle[3], hz[3], vt[3];   // lle = lower_left - eye
+    uint32_t width, height;
+    uint32_t stack_depth;     // LDS traversal-stack entries per lane
+};
+
+struct PassParams {
+    uint32_t n_paths;         // (number of local tiles in the pass) * 64 * n_samples
+    uint32_t npix_pad;        // (number of local tiles in the pass) * 64
+    uint32_t ltile_begin;     // first local tile of the pass
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_index, tile_count;
+    uint32_t s_begin, n_samples;
+    uint32_t ssaa_n;
+    int32_t jitter;
+    float step;
+    float off_x, off_y;
+    uint32_t seed_lo, seed_hi;
+};
+
+}  // namespace rtamd

@@ -1,0 +1,614 @@
+// Wavefront path-tracing kernels for gfx950 (MI355X).  Hand-written HIP, wave = 64.
+//
+//   k_raygen       anti_aliasing.rs:93-124 + camera.rs:62-67 + raytrace.rs:32-37
+//   k_closest_hit  scene.rs:35-52 + intersections.rs:40-190 (BVH instead of the linear scans)
+//   k_shade        materials.rs:28-253 + raytrace.rs:51-96 (iterative form)
+//   k_accumulate   raytrace.rs:134-143 (sum of the samples of a pixel)
+//   k_resolve      raytrace.rs:144-150 + image.rs:29-43
+//
+// (file:line are relative to /root/reference/src/raytracer/.)
+#include "rt_kernels.h"
+
+namespace rtamd {
+namespace {
+
+// ---------------------------------------------------------------- small helpers
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                       // vec3.rs:81-83
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // vec3.rs:104-110
+// vec3.rs:115-121: a zero vector is returned unchanged
+__device__ __forceinline__ f3 normalized(f3 a) {
+    float l2 = dot(a, a);
+    if (l2 == 0.f) return a;
+    float inv = 1.0f / sqrtf(l2);
+    return a * inv;
+}
+__device__ __forceinline__ f3 reflect(f3 v, f3 n) { return v - n * (2.f * dot(v, n)); }   // vec3.rs:129-131
+__device__ __forceinline__ bool near_zero(f3 v) { return fabsf(v.x) < 1e-8f && fabsf(v.y) < 1e-8f && fabsf(v.z) < 1e-8f; }  // vec3.rs:55-58
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// PCG (rxs-m-xs 32): one 32-bit state per path.  The reference's thread_rng stream is not a
+// parity target.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ uint32_t rng_next(uint32_t& s) {
+    s = s * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+// uniform in [0,1) with 24 bits (rng.gen::<f64>() stand-in)
+__device__ __forceinline__ float rng_unit(uint32_t& s) { return (float)(rng_next(s) >> 8) * 0x1p-24f; }
+
+// Uniform direction on the unit sphere.  Same distribution as the reference's
+// normalised rejection sample (vec3.rs:40-52) without the divergent loop.
+__device__ __forceinline__ f3 random_unit_vector(uint32_t& s) {
+    float z = 1.f - 2.f * rng_unit(s);
+    float r = sqrtf(fmaxf(0.f, 1.f - z * z));
+    float u = rng_unit(s);
+    // v_sin_f32 / v_cos_f32 take revolutions
+    return mk(r * __builtin_amdgcn_cosf(u), r * __builtin_amdgcn_sinf(u), z);
+}
+// Uniform point in the unit ball (vec3.rs:40-47): direction * cbrt(u).
+__device__ __forceinline__ f3 random_in_unit_sphere(uint32_t& s) {
+    f3 d = random_unit_vector(s);
+    float u = rng_unit(s);
+    float rad = (u > 0.f) ? __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u) * (1.0f / 3.0f)) : 0.f;
+    return d * rad;
+}
+
+// Wave-level compaction: every lane of the wave must call this (converged).  Lanes with
+// `want` get a unique slot; one atomic per wave.
+__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t per_lane, uint32_t* counter) {
+    const uint64_t m = __ballot(want);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    uint32_t base = 0;
+    if (lane_id() == 0 && cnt) base = atomicAdd(counter, cnt * per_lane);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    return base + rank * per_lane;
+}
+
+// ---------------------------------------------------------------- raygen
+// One thread per path slot.  Path slot pid = s_local * npix_pad + pl, pl = ltile*64 + lane-in-tile:
+// a wave covers one 8x8 pixel tile so that primary rays of a wave are coherent.
+__device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassParams& pp, uint32_t pl, uint32_t& x, uint32_t& row) {
+    const uint32_t lt = pp.ltile_begin + (pl >> 6);
+    const uint32_t l = pl & 63u;
+    const uint64_t gt = (uint64_t)lt * pp.tile_count + pp.tile_index;
+    if (gt >= (uint64_t)pp.tiles_x * pp.tiles_y) return false;
+    const uint32_t ty = (uint32_t)(gt / pp.tiles_x), tx = (uint32_t)(gt - (uint64_t)ty * pp.tiles_x);
+    x = tx * 8u + (l & 7u);
+    row = ty * 8u + (l >> 3);
+    return x < sc.width && row < sc.height;
+}
+
+__global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
+                                                uint32_t* __restrict__ ctl, uint32_t capacity) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < pp.n_paths; pid += stride) {   // n_paths % 64 == 0: wave-uniform
+        const uint32_t s_local = pid / pp.npix_pad;
+        const uint32_t pl = pid - s_local * pp.npix_pad;
+        uint32_t x = 0, row = 0;
+        const bool valid = slot_to_pixel(sc, pp, pl, x, row);
+        radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 A, B, C;
+        if (valid) {
+            const uint32_t s = pp.s_begin + s_local;
+            const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
+            uint32_t rng = pcg_hash(pcg_hash(pcg_hash((row * sc.width + x) ^ pp.seed_lo) + s) ^ pp.seed_hi);
+            float fx = (float)si * pp.step + pp.off_x, fy = (float)sj * pp.step + pp.off_y;
+            if (pp.jitter) {                                              // anti_aliasing.rs:117-120, gen_range(0.0..step)
+                fx += rng_unit(rng) * pp.step;
+                fy += rng_unit(rng) * pp.step;
+            }
+            const float xi = (float)x, yj = (float)(sc.height - 1u - row);   // raytrace.rs:128: output row 0 is j = height-1
+            // camera.rs:62-67: lower_left + horizontal*x + vertical*y - eye; integer and fractional parts kept apart
+            f3 d = mk(sc.lle[0], sc.lle[1], sc.lle[2]) + mk(sc.hz[0], sc.hz[1], sc.hz[2]) * xi + mk(sc.vt[0], sc.vt[1], sc.vt[2]) * yj;
+            d = d + (mk(sc.hz[0], sc.hz[1], sc.hz[2]) * fx + mk(sc.vt[0], sc.vt[1], sc.vt[2]) * fy);
+            d = normalized(d);                                            // raytrace.rs:32-37
+            A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], d.x);
+            B = make_float4(d.y, d.z, __uint_as_float(SRC_NONE), __uint_as_float(pid));
+            C = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+        }
+        const uint32_t slot = wave_alloc(valid, 1u, &ctl[CTL_QCOUNT + 0]);
+        if (valid && slot < capacity) {
+            q.a[slot] = A;
+            q.b[slot] = B;
+            q.c[slot] = C;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- closest hit
+struct Best {
+    float t;
+    uint32_t code;   // HIT_MISS, prim index (leaf order) or HIT_PLANE_BIT | plane
+    uint32_t gid;    // tie-break key
+    float a, b;      // barycentrics (triangles)
+};
+
+// scene.rs:43 / intersections.rs:170: strict '>' while scanning in object/triangle order
+// == smallest t, then smallest scan rank.
+__device__ __forceinline__ void consider(Best& best, float t, uint32_t code, uint32_t gid, float a, float b) {
+    if (t < best.t || (t == best.t && gid < best.gid)) {
+        best.t = t; best.code = code; best.gid = gid; best.a = a; best.b = b;
+    }
+}
+
+// intersections.rs:40-80 in f64 (the reference's own number type): the f32 form of
+// c = |oc|^2 - r^2 cancels catastrophically for the large spheres the scenes use
+// (radius 1000 ground, radius 100 light at distance 866).  from_self: the ray starts
+// on this very sphere, so one root is 0 (rejected by the reference's t > 1e-5) and the
+// other is -b/a exactly.
+__device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
+    const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+    const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+    const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+    const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+    const double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
+    const double dx = d.x, dy = d.y, dz = d.z;
+    const double a = dx * dx + dy * dy + dz * dz;
+    const double hb = dx * ocx + dy * ocy + dz * ocz;   // b/2
+    if (from_self) {
+        const double t = -2.0 * hb / a;
+        return t > 1e-5 ? (float)t : -1.f;
+    }
+    const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
+    const double disc = hb * hb - a * c;
+    if (!(disc >= 0.0)) return -1.f;
+    const double sq = sqrt(disc);
+    const double t1 = (-hb - sq) / a, t2 = (-hb + sq) / a;
+    if (t1 > 1e-5) return (float)t1;
+    if (t2 > 1e-5) return (float)t2;
+    return -1.f;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
+                                                    int it, uint32_t capacity) {
+    extern __shared__ uint32_t lds_stack[];   // [wave][level][lane]: conflict-free per-lane stacks
+    const uint32_t lane = lane_id();
+    uint32_t* const stk = lds_stack + (threadIdx.x >> 6) * (sc.stack_depth * 64u) + lane;
+    const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
+    const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ prims = sc.prims;
+    uint32_t cnt_nodes = 0, cnt_prims = 0;
+
+    for (;;) {
+        // persistent waves: fetch the next 64 rays
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 A = q.a[i], B = q.b[i];
+            const f3 o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
+            const uint32_t src = __float_as_uint(B.z);
+            Best best;
+            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
+
+            // planes: short linear list (they are unbounded).  intersections.rs:82-104
+            for (uint32_t p = 0; p < sc.n_planes; ++p) {
+                const float4 P0 = sc.planes[2 * p], P1 = sc.planes[2 * p + 1];
+                const f3 nrm = mk(P1.x, P1.y, P1.z);
+                const float dn = dot(nrm, d);
+                if (fabsf(dn) < 1e-6f) continue;
+                if (src == (HIT_PLANE_BIT | p)) continue;   // t would be ~0 < 1e-5 in the reference's f64
+                const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
+                if (!(t >= 1e-5f)) continue;
+                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
+            }
+
+            if (sc.n_prims) {
+                const float ooeps = 0x1p-80f;
+                const float idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+                const float idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+                const float idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+                int32_t node = 0;        // root is always an inner node
+                uint32_t sp = 0;
+                for (;;) {
+                    if (node >= 0) {
+                        const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+                        if (COUNT) cnt_nodes++;
+                        // slab tests of both children over [0, best.t]
+                        float ax = (n0.x - o.x) * idx, bx = (n0.y - o.x) * idx;
+                        float ay = (n0.z - o.y) * idy, by = (n0.w - o.y) * idy;
+                        float az = (n2.x - o.z) * idz, bz = (n2.y - o.z) * idz;
+                        const float near0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+                        const float far0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
+                        ax = (n1.x - o.x) * idx; bx = (n1.y - o.x) * idx;
+                        ay = (n1.z - o.y) * idy; by = (n1.w - o.y) * idy;
+                        az = (n2.z - o.z) * idz; bz = (n2.w - o.z) * idz;
+                        const float near1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+                        const float far1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
+                        const bool h0 = near0 <= far0, h1 = near1 <= far1;
+                        const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                        if (h0 && h1) {
+                            const bool first0 = near0 <= near1;
+                            stk[sp * 64u] = (uint32_t)(first0 ? c1 : c0);
+                            sp++;
+                            node = first0 ? c0 : c1;
+                            continue;
+                        }
+                        if (h0) { node = c0; continue; }
+                        if (h1) { node = c1; continue; }
+                    } else {
+                        // leaf: ~node = (first << 3) | (count - 1)
+                        const uint32_t code = (uint32_t)~node;
+                        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+                        for (uint32_t k = 0; k < count; ++k) {
+                            const uint32_t pi = first + k;
+                            const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
+                            if (COUNT) cnt_prims++;
+                            const uint32_t gid = __float_as_uint(r2.y);
+                            if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                                // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
+                                // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
+                                const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                                const f3 pv = cross(d, e2);
+                                const float det = dot(e1, pv);
+                                const f3 tv = o - v0;
+                                const f3 qv = cross(tv, e1);
+                                const float inv = 1.0f / det;
+                                const float a = dot(tv, pv) * inv, b = dot(d, qv) * inv, t = dot(e2, qv) * inv;
+                                if (det != 0.f && a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f) consider(best, t, pi, gid, a, b);
+                            } else {
+                                const float t = sphere_hit(r0, r1, o, d, src == pi);
+                                if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
+                            }
+                        }
+                    }
+                    if (sp == 0) break;
+                    sp--;
+                    node = (int32_t)stk[sp * 64u];
+                }
+            }
+            hits[i] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+        }
+    }
+    if (COUNT) {
+        // wave reduction, one 64-bit add per wave
+        uint64_t cn = cnt_nodes, cp = cnt_prims;
+        for (int off = 32; off > 0; off >>= 1) {
+            cn += __shfl_down(cn, off);
+            cp += __shfl_down(cp, off);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl[CTL_NODES_LO]), (unsigned long long)cn);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl[CTL_PRIMS_LO]), (unsigned long long)cp);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- shading
+// materials.rs:197-230 bilinear texture lookup; texel = byte/255.999 (image.rs:45-51).
+// With integral coordinates floor == ceil and the weights collapse to the exact texel, so
+// the reference's two branches are one formula.  Out-of-range indices (u == 1 or v == 0,
+// where the reference would panic) are clamped.
+__device__ __forceinline__ f3 texture_albedo(const DevScene& sc, int tex, float u, float v) {
+    const int4 T = sc.textures[tex];
+    const float W = (float)T.y, H = (float)T.z;
+    const float x = W * u, y = H - H * v;
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf, x1 = (int)ceilf(x), y1 = (int)ceilf(y);
+    const float fx = x - xf, fy = y - yf;
+    const int last = T.y * T.z - 1;
+    auto px = [&](int xx, int yy) {
+        int idx = yy * T.y + xx;
+        idx = idx < 0 ? 0 : (idx > last ? last : idx);
+        const uchar4 c = sc.texels[T.x + idx];
+        const float k = (float)(1.0 / 255.999);
+        return mk((float)c.x * k, (float)c.y * k, (float)c.z * k);
+    };
+    const f3 c00 = px(x0, y0), c01 = px(x0, y1), c10 = px(x1, y0), c11 = px(x1, y1);
+    return c00 * ((1.f - fx) * (1.f - fy)) + c10 * (fx * (1.f - fy)) + c01 * ((1.f - fx) * fy) + c11 * (fx * fy);
+}
+
+// materials.rs:105-110
+__device__ __forceinline__ f3 refract(f3 dir, f3 n, float ratio) {
+    const float cos_theta = fminf(dot(n, -dir), 1.f);
+    const f3 perp = (dir + n * cos_theta) * ratio;
+    const f3 par = n * -sqrtf(fabsf(1.f - dot(perp, perp)));
+    return perp + par;
+}
+// materials.rs:113-116
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
+    float r0 = (1.f - ref_idx) / (1.f + ref_idx);
+    r0 = r0 * r0;
+    const float x = 1.f - cosine;
+    return r0 + (1.f - r0) * (x * x * x * x * x);
+}
+
+__device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radiance, uint32_t pid, f3 c) {
+    if (sc.n_lights == 0) {
+        // without lights a path contributes exactly once (when it ends): plain 16-byte store
+        radiance[pid] = make_float4(c.x, c.y, c.z, 0.f);
+    } else {
+        // shadow rays of one path end in different lanes / launches
+        float* r = reinterpret_cast<float*>(radiance + pid);
+        atomicAdd(r + 0, c.x);
+        atomicAdd(r + 1, c.y);
+        atomicAdd(r + 2, c.z);
+    }
+}
+
+// One thread per ray of iteration `it`.  last != 0: this is the last allowed bounce
+// (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
+// scattered ray is worthless (it would return black at depth == max_depth) and only the
+// light-sampling branch of raytrace.rs:74-87 can continue the path.
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const float4* __restrict__ hits, RayQueue qo,
+                                               float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
+                                               uint32_t capacity) {
+    const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
+    const uint32_t n_pad = (n + 63u) & ~63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {   // wave-uniform trip count
+        bool emit = false;       // continue with a scattered ray
+        bool fire = false;       // spawn shadow rays
+        f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
+        uint32_t rng = 0, pid = 0, code = HIT_MISS;
+        if (i < n) {
+            const float4 A = qi.a[i], B = qi.b[i], C = qi.c[i], H = hits[i];
+            const f3 o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
+            pid = __float_as_uint(B.w);
+            thr = mk(C.x, C.y, C.z);
+            rng = __float_as_uint(C.w);
+            code = __float_as_uint(H.y);
+            if (code == HIT_MISS) {
+                add_radiance(sc, radiance, pid, thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]));   // raytrace.rs:95
+            } else {
+                const float t = H.x;
+                p = o + d * t;                                                             // raytrace.rs:40-42
+                f3 nrm;
+                int mat;
+                float u = 0.f, v = 0.f;
+                if (code & HIT_PLANE_BIT) {
+                    const float4 P1 = sc.planes[2 * (code & ~HIT_PLANE_BIT) + 1];
+                    nrm = mk(P1.x, P1.y, P1.z);                                            // intersections.rs:96 (as given)
+                    mat = __float_as_int(P1.w);
+                } else {
+                    const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
+                    const int4 M = sc.meta[code];
+                    mat = M.z;
+                    if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                        const f3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                        nrm = normalized(cross(e1, e2));                                   // intersections.rs:169
+                        if (M.w >= 0) {                                                    // intersections.rs:177-183
+                            const float* uv = sc.uvs + 6 * (size_t)M.w;
+                            const float a = H.z, b = H.w, c = 1.f - a - b;
+                            u = a * uv[2] + b * uv[4] + c * uv[0];
+                            v = a * uv[3] + b * uv[5] + c * uv[1];
+                        }
+                    } else {
+                        const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+                        const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+                        const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+                        const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+                        const float ir = (float)(1.0 / rad);
+                        nrm = mk((float)((double)p.x - cx), (float)((double)p.y - cy), (float)((double)p.z - cz)) * ir;  // intersections.rs:69
+                    }
+                }
+                const float4 M0 = sc.materials[2 * mat], M1 = sc.materials[2 * mat + 1];
+                const int mtype = __float_as_int(M1.x);
+                f3 albedo = mk(M0.x, M0.y, M0.z);
+                bool scattered = false;
+                if (mtype == 4) {                                   // Emissive, materials.rs:80-88
+                    add_radiance(sc, radiance, pid, thr * albedo);  // raytrace.rs:90
+                } else if (mtype == 0) {                            // Lambertian, materials.rs:52-66
+                    f3 dir = nrm + random_unit_vector(rng);
+                    if (near_zero(dir)) dir = nrm;
+                    ndir = normalized(dir);
+                    scattered = true;
+                } else if (mtype == 1) {                            // Metal, materials.rs:168-183
+                    const f3 refl = reflect(normalized(d), nrm);
+                    ndir = normalized(refl + random_in_unit_sphere(rng) * M0.w);
+                    scattered = dot(ndir, nrm) > 0.f;               // else None: the path ends black (raytrace.rs:92)
+                } else if (mtype == 2) {                            // Dieletrics, materials.rs:119-153
+                    const bool front = dot(nrm, d) <= 0.f;
+                    const float ratio = front ? 1.0f / M0.w : M0.w;
+                    const f3 nn = front ? nrm : -nrm;
+                    const float cos_theta = fminf(dot(-d, nn), 1.f);
+                    const float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+                    const bool cannot_refract = ratio * sin_theta > 1.f;
+                    f3 dir = refract(d, nn, ratio);
+                    // the RNG draw is skipped when cannot_refract (short circuit, materials.rs:143-144)
+                    if (cannot_refract || reflectance(cos_theta, ratio) > rng_unit(rng)) dir = reflect(d, nn);
+                    ndir = normalized(dir);
+                    scattered = true;
+                } else {                                            // Texture, materials.rs:233-253
+                    albedo = texture_albedo(sc, __float_as_int(M1.y), u, v);
+                    if (dot(d, nrm) > 0.f) {
+                        add_radiance(sc, radiance, pid, thr * albedo);   // back face emits the texel
+                    } else {
+                        f3 dir = nrm + random_unit_vector(rng);
+                        if (near_zero(dir) || dot(nrm, dir) <= 0.f) dir = nrm;
+                        ndir = normalized(dir);
+                        scattered = true;
+                    }
+                }
+                if (scattered) {
+                    if (!last) {
+                        thr = thr * albedo;                         // raytrace.rs:88, light_color is black before the last bounce
+                        emit = true;
+                    } else if (sc.n_lights) {
+                        // raytrace.rs:64-87
+                        const float prob = (mtype == 2) ? 0.05f : 0.1f;
+                        const float L = (float)sc.n_lights;
+                        if (rng_unit(rng) > 1.f - L * prob) {
+                            fire = true;
+                            thr = thr * albedo * (1.0f / L);        // albedo * target / lights_len
+                        }
+                    }
+                }
+            }
+        }
+        if (!last) {
+            const uint32_t slot = wave_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1]);
+            if (emit) {
+                if (slot < capacity) {
+                    qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
+                    qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(code), __uint_as_float(pid));
+                    qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
+                } else {
+                    atomicAdd(&ctl[CTL_OVERFLOW], 1u);
+                }
+            }
+        } else if (sc.n_lights) {
+            const uint32_t L = sc.n_lights;
+            const uint32_t slot0 = wave_alloc(fire, L, &ctl[CTL_QCOUNT + it + 1]);
+            if (fire) {
+                for (uint32_t l = 0; l < L; ++l) {
+                    const uint32_t slot = slot0 + l;
+                    if (slot >= capacity) { atomicAdd(&ctl[CTL_OVERFLOW], 1u); continue; }
+                    const float4 Lp = sc.lights[l];
+                    const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
+                    qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
+                    qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(code), __uint_as_float(pid));
+                    qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pcg_hash(rng + 0x9E3779B9u * (l + 1u))));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- accumulate / resolve
+// raytrace.rs:134-143: sum of the sample colours of a pixel, in a fixed order.
+__global__ __launch_bounds__(256) void k_accumulate(DevScene sc, PassParams pp, const float4* __restrict__ radiance,
+                                                    float* __restrict__ accum) {
+    const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl >= pp.npix_pad) return;
+    uint32_t x, row;
+    if (!slot_to_pixel(sc, pp, pl, x, row)) return;
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (uint32_t s = 0; s < pp.n_samples; ++s) {
+        const float4 c = radiance[(size_t)s * pp.npix_pad + pl];
+        r += c.x; g += c.y; b += c.z;
+    }
+    float* dst = accum + ((size_t)row * sc.width + x) * 3u;
+    dst[0] += r; dst[1] += g; dst[2] += b;
+}
+
+// raytrace.rs:144-150: mean, sqrt gamma, clamp to <= 1 (no lower clamp);
+// image.rs:37-43: (255.999 * c) as u8, saturating, NaN -> 0.
+__device__ __forceinline__ uint8_t to_output(float c) {
+    const float v = 255.999f * c;
+    if (!(v == v)) return 0;
+    if (v <= 0.f) return 0;
+    if (v >= 255.f) return 255;
+    return (uint8_t)v;
+}
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, uint32_t n_values, float inv_spp,
+                                                 uint8_t* __restrict__ rgb8, float* __restrict__ color) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_values) return;
+    // f64::min(NaN, 1.0) == 1.0 in Rust, as fminf does here
+    const float c = fminf(sqrtf(accum[i] * inv_spp), 1.0f);
+    if (color) color[i] = c;
+    if (rgb8) rgb8[i] = to_output(c);
+}
+
+// per-pixel hit record for rt_primary_hits
+__global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, RayQueue q, const float4* __restrict__ hits,
+                                                  const uint32_t* __restrict__ ctl, uint32_t capacity, int32_t* __restrict__ obj,
+                                                  int32_t* __restrict__ tri, float* __restrict__ tout, float* __restrict__ nout) {
+    const uint32_t n = min(ctl[CTL_QCOUNT + 0], capacity);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 A = q.a[i], B = q.b[i], H = hits[i];
+    const uint32_t pid = __float_as_uint(B.w);
+    uint32_t x, row;
+    if (!slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
+    const size_t px = (size_t)row * sc.width + x;
+    const uint32_t code = __float_as_uint(H.y);
+    int32_t o = -1, t = -1;
+    float tt = -1.f;
+    f3 nrm = mk(0, 0, 0);
+    if (code != HIT_MISS) {
+        tt = H.x;
+        if (code & HIT_PLANE_BIT) {
+            const uint32_t p = code & ~HIT_PLANE_BIT;
+            const float4 P1 = sc.planes[2 * p + 1];
+            nrm = mk(P1.x, P1.y, P1.z);
+            o = sc.plane_object[p];
+        } else {
+            const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
+            const int4 M = sc.meta[code];
+            o = M.x; t = M.y;
+            if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                nrm = normalized(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));
+            } else {
+                const f3 org = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
+                const f3 p = org + d * tt;
+                const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+                const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+                const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+                const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+                const float ir = (float)(1.0 / rad);
+                nrm = mk((float)((double)p.x - cx), (float)((double)p.y - cy), (float)((double)p.z - cz)) * ir;
+            }
+        }
+    }
+    obj[px] = o; tri[px] = t; tout[px] = tt;
+    nout[px * 3 + 0] = nrm.x; nout[px * 3 + 1] = nrm.y; nout[px * 3 + 2] = nrm.z;
+}
+
+// adds the pass's counters into the persistent 64-bit statistics
+__global__ void k_stats(const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ stats, uint32_t capacity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < CTL_MAX_IT) stats[i] += min(ctl[CTL_QCOUNT + i], capacity);
+    if (i == CTL_MAX_IT) stats[i] += ctl[CTL_OVERFLOW];
+    if (i == CTL_MAX_IT + 1) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_NODES_LO]);
+    if (i == CTL_MAX_IT + 2) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_PRIMS_LO]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launch wrappers
+static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue q, float4* radiance, uint32_t* ctl,
+                   uint32_t capacity, hipStream_t st) {
+    uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
+}
+void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float4* hits, uint32_t* ctl, int it, uint32_t capacity,
+                        uint32_t max_rays, bool counters, hipStream_t st) {
+    const size_t lds = (size_t)4 * 64 * sc.stack_depth * sizeof(uint32_t);
+    uint32_t per_cu = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
+    if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
+    else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
+}
+void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float4* hits, RayQueue qo, float4* radiance,
+                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
+    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 8u, std::max<uint32_t>(1, cdiv(max_rays, 256)));
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+}
+void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
+}
+void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3(cdiv(n_values, 256)), dim3(256), 0, st, accum, n_values, inv_spp, rgb8, color);
+}
+void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float4* hits, const uint32_t* ctl, uint32_t capacity,
+                     int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st) {
+    hipLaunchKernelGGL(k_hit_info, dim3(cdiv(pp.n_paths, 256)), dim3(256), 0, st, sc, pp, q, hits, ctl, capacity, obj, tri, t, nrm);
+}
+void launch_stats(const uint32_t* ctl, unsigned long long* stats, uint32_t capacity, hipStream_t st) {
+    hipLaunchKernelGGL(k_stats, dim3(cdiv(CTL_MAX_IT + 3, 64)), dim3(64), 0, st, ctl, stats, capacity);
+}
+
+}  // namespace rtamd

@@ -1,0 +1,287 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same scenes.
+
+Bars (BASELINE.json north_star):
+  * primary-ray closest-hit object / triangle ids: bit-exact on the reference's fixtures
+  * hit distance and normal: within 1e-5 relative
+  * converged images: PSNR >= 40 dB against the oracle at matched high spp (RNG streams differ)
+plus size-independent properties (tile/sample-split linearity, determinism, ray accounting)
+and the edge cases (depth 0, empty scene, odd image sizes, single primitives)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from util import GOLDEN, pkg, sub
+
+pytestmark = pytest.mark.gpu
+
+rt = pkg()
+scenegen = sub("scenegen")
+
+REL_TOL = 1e-5   # north_star: hit distance and normal within 1e-5 relative
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rt.Context(0)
+    yield c
+    c.close()
+
+
+def load_pair(name, ctx, width=None, height=None):
+    path = os.path.join(GOLDEN, "scenes", name, name + ".yaml")
+    d = O.load_scene_dict(path, base_dir=GOLDEN)
+    if width is None:
+        ctx.upload(rt.Scene.load(path, base_dir=GOLDEN))
+        return O.OracleScene.from_dict(d)
+    # resized variant: rewrite the YAML header only
+    import tempfile
+    text = open(path).read().replace("width: 500", "width: %d" % width).replace("height: 500", "height: %d" % height)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(text)
+    try:
+        ctx.upload(rt.Scene.load(f.name, base_dir=GOLDEN))
+    finally:
+        os.unlink(f.name)
+    d["width"], d["height"] = width, height
+    return O.OracleScene.from_dict(d)
+
+
+def check_hits(got, want, allow_id_mismatch=0):
+    id_bad = (got["object_id"] != want["object_id"]) | (got["triangle_id"] != want["triangle_id"])
+    assert id_bad.sum() <= allow_id_mismatch, "%d hit ids differ from the oracle" % id_bad.sum()
+    ok = (want["object_id"] >= 0) & ~id_bad
+    assert np.all(got["t"][want["object_id"] < 0] == -1.0)
+    rel_t = np.abs(got["t"][ok].astype(np.float64) - want["t"][ok]) / np.abs(want["t"][ok])
+    assert rel_t.max() < REL_TOL, "max relative t error %.3e" % rel_t.max()
+    nerr = np.linalg.norm(got["normal"][ok].astype(np.float64) - want["normal"][ok], axis=-1) / np.linalg.norm(want["normal"][ok], axis=-1)
+    assert nerr.max() < REL_TOL, "max relative normal error %.3e" % nerr.max()
+    return int(id_bad.sum()), float(rel_t.max()), float(nerr.max())
+
+
+# ------------------------------------------------------------------ C2: the hit-id gate
+def test_c2_cube_primary_hits_bit_exact(ctx):
+    osc = load_pair("cube", ctx)
+    got = ctx.primary_hits(0.0, 0.0)
+    want = osc.primary_hits(0.0, 0.0)
+    assert (want["triangle_id"] >= 0).sum() > 10000    # the cube is in view
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=0)
+    print("C2: ids exact, max rel t %.2e, normal %.2e" % (rt_, rn))
+
+
+@pytest.mark.parametrize("off", [(0.5, 0.5), (0.25, 0.75)])
+def test_cube_primary_hits_other_offsets(ctx, off):
+    osc = load_pair("cube", ctx)
+    check_hits(ctx.primary_hits(*off), osc.primary_hits(*off), allow_id_mismatch=0)
+
+
+def test_c1_spheres_primary_hits(ctx):
+    osc = load_pair("spheres", ctx)
+    check_hits(ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0), allow_id_mismatch=0)
+
+
+def test_c3_rtiow_primary_hits(ctx):
+    sc = scenegen.scene_c3(width=480, height=270)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
+    # silhouette rays may flip between f32 rays and the f64 oracle: report, allow a handful
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8)
+    print("C3 480x270: %d id mismatches of %d" % (bad, got["t"].size))
+
+
+def test_c4_torus_primary_hits(ctx):
+    sc = scenegen.scene_c4(width=192, height=108, nu=100, nv=50)    # 10,000 triangles: the oracle is brute force
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
+    assert (want["triangle_id"] >= 0).sum() > 2000
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=4)
+    print("C4 (10k tris) 192x108: %d id mismatches" % bad)
+
+
+# ------------------------------------------------------------------ images
+def psnr(a, b):
+    mse = np.mean((a - b) ** 2)
+    return 10.0 * np.log10(1.0 / mse)
+
+
+def gamma(sum_img, spp):
+    return np.minimum(np.sqrt(sum_img / spp), 1.0)
+
+
+@pytest.mark.parametrize("name,n", [("spheres", 40), ("cube", 40)])
+def test_converged_image_parity(ctx, name, n):
+    """PSNR >= 40 dB between the GPU render and the f64 oracle at matched spp (n*n) on a
+    128x128 version of the reference scene; also no systematic bias."""
+    osc = load_pair(name, ctx, 128, 128)
+    spp = n * n
+    acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=5, seed=3))
+    ref = osc.render(mode="jitter", N=n, depth=5, seed=17)
+    g, o = gamma(acc.astype(np.float64), spp), ref["color"]
+    p = psnr(g, o)
+    bias = abs(np.mean(acc / spp) - np.mean(ref["sum"] / spp))
+    print("%s: PSNR %.2f dB at %d spp, |mean radiance bias| %.2e" % (name, p, spp, bias))
+    assert p >= 40.0
+    assert bias <= 1e-3 * max(1.0, np.mean(ref["sum"] / spp)) * 3
+
+
+def test_c3_image_parity_small(ctx):
+    sc = scenegen.scene_c3(width=160, height=90)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    n = 24
+    acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=5, seed=5))
+    ref = osc.render(mode="jitter", N=n, depth=5, seed=23)
+    p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
+    print("C3 160x90: PSNR %.2f dB at %d spp" % (p, n * n))
+    assert p >= 38.0
+
+
+def test_golden_plateaus_of_the_reference_renders(ctx):
+    """Deterministic facts of the reference's own PNGs."""
+    from PIL import Image
+    for name, value, minimum in (("spheres", 221, 0.9), ("cube", 114, 0.5)):
+        load_pair(name, ctx)
+        _, rgb = ctx.render_image(rt.RenderParams("uniform:2", depth=5, seed=9))
+        gold = np.asarray(Image.open(os.path.join(GOLDEN, "scenes", name, name + ".png")).convert("RGB"))
+        gm, mm = np.all(gold == value, axis=2), np.all(rgb == value, axis=2)
+        assert (gm & mm).sum() >= minimum * gm.sum(), (name, (gm & mm).sum(), gm.sum())
+
+
+# ------------------------------------------------------------------ properties
+def test_tile_split_union_is_bit_identical(ctx):
+    load_pair("spheres", ctx)
+    full, _ = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=4))
+    parts = np.zeros_like(full)
+    for k in range(3):
+        a, _ = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=4, tile_index=k, tile_count=3))
+        assert np.all((a == 0) | (parts == 0))     # disjoint
+        parts += a
+    assert np.array_equal(parts, full)
+
+
+def test_sample_split_is_linear(ctx):
+    load_pair("spheres", ctx)
+    full, _ = ctx.render_image(rt.RenderParams("jitter:4", depth=5, seed=8))
+    a, _ = ctx.render_image(rt.RenderParams("jitter:4", depth=5, seed=8, sample_begin=0, sample_end=5))
+    b, _ = ctx.render_image(rt.RenderParams("jitter:4", depth=5, seed=8, sample_begin=5, sample_end=16))
+    assert np.allclose(a + b, full, rtol=1e-5, atol=1e-6)
+
+
+def test_small_passes_equal_one_big_pass(ctx):
+    load_pair("cube", ctx)
+    one, _ = ctx.render_image(rt.RenderParams("jitter:3", depth=4, seed=2))
+    many, _ = ctx.render_image(rt.RenderParams("jitter:3", depth=4, seed=2, max_paths_per_pass=64 * 100))
+    assert np.allclose(one, many, rtol=1e-5, atol=1e-6)
+
+
+def test_ray_accounting_and_determinism(ctx):
+    load_pair("cube", ctx)
+    ctx.stats_reset()
+    a, rgb_a = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=1, counters=True, timing=True))
+    st = ctx.stats()
+    assert st["rays_per_iteration"][0] == 500 * 500 * 4 == st["paths"]
+    assert all(x >= y for x, y in zip(st["rays_per_iteration"][:5], st["rays_per_iteration"][1:5]))
+    assert st["queue_overflow"] == 0 and st["nodes_visited"] > 0 and st["prims_tested"] > 0 and st["hit_ms"] > 0
+    b, rgb_b = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=1))
+    # contributions of shadow rays are float atomics: order may change the last bits only
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6) and np.abs(rgb_a.astype(int) - rgb_b.astype(int)).max() <= 1
+    c, _ = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=2))
+    assert not np.array_equal(a, c)
+
+
+def test_device_pointer_api_matches_host_api(ctx):
+    import torch
+    load_pair("spheres", ctx)
+    p = rt.RenderParams("jitter:2", depth=3, seed=6)
+    acc_h, rgb_h = ctx.render_image(p)
+    acc = torch.zeros((ctx.height, ctx.width, 3), dtype=torch.float32, device="cuda:0")
+    ctx.render_accumulate(p, acc)
+    rgb = ctx.resolve(acc, 4)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), acc_h, rtol=1e-5, atol=1e-6)
+    assert np.abs(rgb.cpu().numpy().astype(int) - rgb_h.astype(int)).max() <= 1
+
+
+# ------------------------------------------------------------------ edge cases
+CAM = dict(eye=[0.0, 0.0, 5.0], look_at=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)
+
+
+def small_scene(ctx, objects, w=37, h=21, bg=(0.25, 0.5, 1.0)):
+    ctx.upload(rt.Scene.from_objects(w, h, list(bg), CAM, objects))
+    return O.OracleScene.from_dict(dict(width=w, height=h, background=list(bg), camera=CAM, objects=[
+        (dict(type="Mesh", materials=o["materials"], mesh=dict(verts_np=o["verts"], tris_np=o["tris"], tri_mat_np=np.zeros(len(o["tris"]), np.int64)))
+         if o["type"] == "Mesh" else o) for o in objects]))
+
+
+def test_depth_zero_is_black(ctx):
+    small_scene(ctx, [dict(type="Sphere", center=[0, 0, 0], radius=1.0, material=dict(type="Emissive", color=[1, 1, 1]))])
+    acc, rgb = ctx.render_image(rt.RenderParams("jitter:2", depth=0))
+    assert not acc.any() and not rgb.any()     # raytrace.rs:52-54
+
+
+def test_empty_scene_is_background(ctx):
+    osc = small_scene(ctx, [])
+    acc, rgb = ctx.render_image(rt.RenderParams("jitter:2", depth=5))
+    assert np.allclose(acc / 4, [0.25, 0.5, 1.0])
+    assert np.array_equal(rgb, osc.render(N=2, depth=5)["rgb8"])
+    h = ctx.primary_hits()
+    assert np.all(h["object_id"] == -1) and np.all(h["t"] == -1)
+
+
+def test_single_primitives_and_odd_sizes(ctx):
+    tri = dict(type="Mesh", verts=np.array([[-1.0, -1, 0], [1, -1, 0], [0, 1.5, 0.5]]), tris=np.array([[0, 1, 2]]),
+               materials=[dict(type="Emissive", color=[0.5, 0.25, 1.0])])
+    for objs in ([tri], [dict(type="Sphere", center=[0.2, 0.1, 0], radius=1.3, material=dict(type="Emissive", color=[1, 0.5, 0.25]))],
+                 [dict(type="Plane", center=[0, -1, 0], normal=[0, 1, 0], material=dict(type="Emissive", color=[0.5, 0.5, 0.5]))],
+                 [tri, dict(type="Sphere", center=[0, 0, -3], radius=2.0, material=dict(type="Emissive", color=[1, 1, 1])),
+                  dict(type="Plane", center=[0, -1, 0], normal=[0, 1, 0], material=dict(type="Emissive", color=[0.5, 0.5, 0.5]))]):
+        for (w, h) in ((1, 1), (37, 21), (8, 8)):
+            osc = small_scene(ctx, objs, w, h)
+            check_hits(ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5))
+            # purely emissive scenes are deterministic at the uniform grid: images must agree to the byte
+            _, rgb = ctx.render_image(rt.RenderParams("grid:2", depth=3))
+            want = osc.render(mode="uniform", N=2, depth=3)["rgb8"]
+            assert np.abs(rgb.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_tie_break_prefers_lower_object_index(ctx):
+    """scene.rs:43 strict '>': two coincident emissive triangles / spheres -> the first object wins."""
+    v = np.array([[-1.0, -1, 0], [1, -1, 0], [0, 1, 0]])
+    objs = [dict(type="Mesh", verts=v, tris=np.array([[0, 1, 2]]), materials=[dict(type="Emissive", color=[1, 0, 0])]),
+            dict(type="Mesh", verts=v, tris=np.array([[0, 1, 2]]), materials=[dict(type="Emissive", color=[0, 1, 0])]),
+            dict(type="Sphere", center=[0, 0, -4], radius=1.0, material=dict(type="Emissive", color=[0, 0, 1])),
+            dict(type="Sphere", center=[0, 0, -4], radius=1.0, material=dict(type="Emissive", color=[1, 1, 1]))]
+    osc = small_scene(ctx, objs, 64, 64)
+    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    check_hits(got, want)
+    assert set(np.unique(got["object_id"])) <= {-1, 0, 2}
+
+
+def test_invalid_arguments_are_errors(ctx):
+    load_pair("cube", ctx)
+    with pytest.raises(rt.RtError):
+        ctx.render_image(rt.RenderParams(rt.SuperSampling("Jitter", 0)))
+    with pytest.raises(rt.RtError):
+        ctx.render_image(rt.RenderParams("jitter:2", depth=256))
+    with pytest.raises(rt.RtError):
+        ctx.render_image(rt.RenderParams("jitter:2", sample_begin=3, sample_end=99))
+    with pytest.raises(rt.RtError):
+        ctx.render_image(rt.RenderParams("jitter:2", tile_index=2, tile_count=2))
+
+
+def test_compute_image_drop_in(ctx, tmp_path):
+    """raytracer::compute_image with the reference's four arguments writes the PNG."""
+    from PIL import Image
+    out = tmp_path / "sub" / "spheres.png"
+    rt.compute_image("uniform:2", 5, os.path.join(GOLDEN, "scenes/spheres/spheres.yaml"), str(out), base_dir=GOLDEN)
+    img = np.asarray(Image.open(out))
+    assert img.shape == (500, 500, 3)
+    gold = np.asarray(Image.open(os.path.join(GOLDEN, "scenes/spheres/spheres.png")).convert("RGB"))
+    mse = np.mean((img.astype(float) - gold.astype(float)) ** 2)
+    assert 10 * np.log10(255.0 ** 2 / mse) > 25.0
+    with pytest.raises(rt.SSAADecodeError):
+        rt.compute_image("bogus", 5, "x.yaml", str(out))
