@@ -343,9 +343,9 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
     for (int k = 0; k < 3; ++k) {
         sc.bg[k] = (float)d->background[k];
         sc.eye[k] = (float)d->cam_eye[k];
-        sc.lle[k] = (float)(d->cam_lower_left[k] - d->cam_eye[k]);
-        sc.hz[k] = (float)d->cam_horizontal[k];
-        sc.vt[k] = (float)d->cam_vertical[k];
+        sc.lle[k] = d->cam_lower_left[k] - d->cam_eye[k];
+        sc.hz[k] = d->cam_horizontal[k];
+        sc.vt[k] = d->cam_vertical[k];
     }
     sc.width = d->width; sc.height = d->height;
     sc.stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2);
@@ -396,7 +396,16 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             if (pp_out) *pp_out = pp;
             HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
             launch_raygen(ctx->cfg, sc, pp, ctx->q[0], ctx->radiance, ctx->ctl, capacity, st);
-            ctx->paths_total += pp.n_paths;
+            {   // primary rays = pixels of the pass's tiles that lie inside the image
+                uint64_t px = 0;
+                for (uint32_t lt = lt0; lt < lt0 + nt; ++lt) {
+                    const uint64_t gt = (uint64_t)lt * tcount + p->tile_index;
+                    if (gt >= n_tiles) break;
+                    const uint32_t ty = (uint32_t)(gt / tiles_x), tx = (uint32_t)(gt % tiles_x);
+                    px += (uint64_t)std::min(8u, sc.width - tx * 8) * std::min(8u, sc.height - ty * 8);
+                }
+                ctx->paths_total += px * ns;
+            }
             const uint32_t depth = hits_only ? 1u : p->depth;
             const uint32_t iters = depth ? depth + gens : 0u;          // raytrace.rs:52-54: depth 0 traces nothing
             for (uint32_t it = 0; it < iters; ++it) {

@@ -16,9 +16,10 @@ constexpr int CTL_MAX_IT = 320;               // == RT_MAX_ITERATIONS
 constexpr int CTL_QCOUNT = 0;                 // [it]   rays in the queue consumed by iteration `it`
 constexpr int CTL_FETCH = CTL_MAX_IT + 8;     // [it]   dynamic-fetch cursor of the closest-hit kernel
 constexpr int CTL_OVERFLOW = 2 * (CTL_MAX_IT + 8);
-constexpr int CTL_NODES_LO = CTL_OVERFLOW + 1;   // 64-bit counters as two words (lo, hi)
-constexpr int CTL_PRIMS_LO = CTL_OVERFLOW + 3;
+constexpr int CTL_NODES_LO = CTL_OVERFLOW + 2;   // 64-bit counters: even word index = 8-byte aligned
+constexpr int CTL_PRIMS_LO = CTL_OVERFLOW + 4;
 constexpr int CTL_WORDS = CTL_OVERFLOW + 8;
+static_assert(CTL_NODES_LO % 2 == 0 && CTL_PRIMS_LO % 2 == 0, "64-bit counters must be 8-byte aligned");
 
 // Ray queue, structure of arrays of 16-byte words so that every wave-level access
 // is one contiguous 1 KiB transaction:
@@ -55,7 +56,10 @@ struct DevScene {
     const float4* lights;     // xyz of sample_points[0]
     uint32_t n_lights;
     float bg[3];
-    float eye[3], lle[3], hz[3], vt[3];   // lle = lower_left - eye
+    float eye[3];
+    // primary-ray directions are formed in f64 (the reference's type) and rounded once:
+    // an f32 camera loses 1e-4 relative in t on grazing rays
+    double lle[3], hz[3], vt[3];          // lle = lower_left - eye
     uint32_t width, height;
     uint32_t stack_depth;     // LDS traversal-stack entries per lane
 };

@@ -113,11 +113,15 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
                 fx += rng_unit(rng) * pp.step;
                 fy += rng_unit(rng) * pp.step;
             }
-            const float xi = (float)x, yj = (float)(sc.height - 1u - row);   // raytrace.rs:128: output row 0 is j = height-1
-            // camera.rs:62-67: lower_left + horizontal*x + vertical*y - eye; integer and fractional parts kept apart
-            f3 d = mk(sc.lle[0], sc.lle[1], sc.lle[2]) + mk(sc.hz[0], sc.hz[1], sc.hz[2]) * xi + mk(sc.vt[0], sc.vt[1], sc.vt[2]) * yj;
-            d = d + (mk(sc.hz[0], sc.hz[1], sc.hz[2]) * fx + mk(sc.vt[0], sc.vt[1], sc.vt[2]) * fy);
-            d = normalized(d);                                            // raytrace.rs:32-37
+            // camera.rs:62-67 in f64: lower_left + horizontal*x + vertical*y - eye, then Ray::new's
+            // normalisation (raytrace.rs:32-37); raytrace.rs:128: output row 0 is j = height-1
+            const double px = (double)x + (double)fx, py = (double)(sc.height - 1u - row) + (double)fy;
+            const double ddx = sc.lle[0] + sc.hz[0] * px + sc.vt[0] * py;
+            const double ddy = sc.lle[1] + sc.hz[1] * px + sc.vt[1] * py;
+            const double ddz = sc.lle[2] + sc.hz[2] * px + sc.vt[2] * py;
+            const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+            const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
+            const f3 d = mk((float)(ddx * inv), (float)(ddy * inv), (float)(ddz * inv));
             A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], d.x);
             B = make_float4(d.y, d.z, __uint_as_float(SRC_NONE), __uint_as_float(pid));
             C = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
@@ -175,6 +179,42 @@ __device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3
     return -1.f;
 }
 
+// The reference's own operation sequence for one triangle (intersections.rs:123-126,153-166),
+// evaluated without FMA contraction.  Whether a ray that STARTS on a triangle re-hits it at
+// t ~ 0 (the reference accepts t >= 0 with no epsilon) is decided by rounding noise, and so is
+// the side of the surface the hit point o + d*t lands on; both depend on the exact sequence of
+// roundings.  Using the reference's sequence for these two values makes the f32 statistics the
+// same as the f64 reference's (measured with the oracle's f32 instantiation).
+__device__ __forceinline__ float det3_ref(f3 v1, f3 v2, f3 v3) {
+#pragma clang fp contract(off)
+    return (v1.x * v2.y * v3.z + v2.x * v3.y * v1.z + v3.x * v1.y * v2.z) - (v3.x * v2.y * v1.z + v2.x * v1.y * v3.z + v1.x * v3.y * v2.z);
+}
+__device__ __forceinline__ f3 sub_ref(f3 a, f3 b) {
+#pragma clang fp contract(off)
+    return mk(a.x - b.x, a.y - b.y, a.z - b.z);
+}
+// t = -(Mt / M) only
+__device__ __forceinline__ float tri_t_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac) {
+#pragma clang fp contract(off)
+    const f3 res = sub_ref(o, A);
+    return -(det3_ref(res, ab, ac) / det3_ref(d, ab, ac));
+}
+__device__ __forceinline__ bool tri_hit_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac, float& t, float& a, float& b) {
+#pragma clang fp contract(off)
+    const f3 res = sub_ref(o, A);
+    const float m = det3_ref(d, ab, ac), mt = det3_ref(res, ab, ac), ma = det3_ref(d, res, ac), mb = det3_ref(d, ab, res);
+    a = ma / m;
+    b = mb / m;
+    t = -(mt / m);
+    // NaN (M == 0) is rejected here; the reference would accept it when no hit exists yet
+    return a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f;
+}
+// raytrace.rs:40-42: origin + direction * t, two roundings
+__device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
+#pragma clang fp contract(off)
+    return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
@@ -210,6 +250,19 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
                 const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
                 if (!(t >= 1e-5f)) continue;
                 consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
+            }
+
+            // a ray that starts on a triangle tests that triangle with the reference's own
+            // operation sequence (see tri_hit_ref); the traversal below skips it
+            if (src < sc.n_prims) {
+                const float4 r2 = prims[3 * src + 2];
+                if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                    const float4 r0 = prims[3 * src], r1 = prims[3 * src + 1];
+                    float t, a, b;
+                    if (COUNT) cnt_prims++;
+                    if (tri_hit_ref(o, d, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), t, a, b))
+                        consider(best, t, src, __float_as_uint(r2.y), a, b);
+                }
             }
 
             if (sc.n_prims) {
@@ -255,6 +308,7 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
                             if (COUNT) cnt_prims++;
                             const uint32_t gid = __float_as_uint(r2.y);
                             if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                                if (pi == src) continue;   // tested above
                                 // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
                                 // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
                                 const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
@@ -370,8 +424,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
             if (code == HIT_MISS) {
                 add_radiance(sc, radiance, pid, thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]));   // raytrace.rs:95
             } else {
-                const float t = H.x;
-                p = o + d * t;                                                             // raytrace.rs:40-42
+                float t = H.x;
                 f3 nrm;
                 int mat;
                 float u = 0.f, v = 0.f;
@@ -379,6 +432,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
                     const float4 P1 = sc.planes[2 * (code & ~HIT_PLANE_BIT) + 1];
                     nrm = mk(P1.x, P1.y, P1.z);                                            // intersections.rs:96 (as given)
                     mat = __float_as_int(P1.w);
+                    p = at_ref(o, d, t);                                                   // raytrace.rs:40-42
                 } else {
                     const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
                     const int4 M = sc.meta[code];
@@ -386,6 +440,9 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
                     if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
                         const f3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
                         nrm = normalized(cross(e1, e2));                                   // intersections.rs:169
+                        // hit point from the reference's own t sequence (see tri_hit_ref)
+                        t = tri_t_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2);
+                        p = at_ref(o, d, t);                                               // intersections.rs:172
                         if (M.w >= 0) {                                                    // intersections.rs:177-183
                             const float* uv = sc.uvs + 6 * (size_t)M.w;
                             const float a = H.z, b = H.w, c = 1.f - a - b;
@@ -398,6 +455,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
                         const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
                         const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
                         const float ir = (float)(1.0 / rad);
+                        p = at_ref(o, d, t);                                               // intersections.rs:68
                         nrm = mk((float)((double)p.x - cx), (float)((double)p.y - cy), (float)((double)p.z - cz)) * ir;  // intersections.rs:69
                     }
                 }

@@ -71,6 +71,14 @@ def load_library():
     if not os.path.exists(path):
         raise RtError("%s is missing: build it with `make -C %s` (python __graft_entry__.py build); there is no CPU fallback"
                       % (path, os.path.join(_HERE, "csrc")))
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as the
+    # system one this library links to).  Importing torch first makes the loader resolve our
+    # dependency to torch's copy; loading the two runtimes side by side leaves the second
+    # without a GPU ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, u32, i32, u64, dbl = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64, C.c_double
     L.rt_context_create.restype = C.c_int
