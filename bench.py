@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the wavefront render path at 1080p on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL = backend "nccl")
+
+Workload (BASELINE.json): the combined scene of config C5 -- ~485 RTIOW spheres + the
+1,000,000-triangle torus -- at 1920x1080, depth 5, jittered 64x64 sample grid.  One STEP =
+one pass of the hot path over one batch: `--spp-per-step` (default 64) samples per pixel
+of the full frame on every rank (a disjoint cell range of the 64x64 grid per rank and step:
+the C5 "sample split"), followed by the RCCL sum-reduce of the f32 accumulators to rank 0
+and the resolve there.  Per-GPU work is fixed as N grows => weak scaling.  `--workload c3`
+(spheres only) and `--workload c4` (torus + plane at 3840x2160, tile split with
+`--split tiles`) are available for the other configs.
+
+value = rays actually traced by all ranks (primary + scattered + shadow) / wall time.
+Rays are counted on the device by the queue counters (rt_get_stats).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c5", choices=["c3", "c4", "c5"])
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--split", default=None, choices=["spp", "tiles"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-step", type=int, default=6, help="cpu_baseline traces every n-th pixel and row")
+    ap.add_argument("--small", action="store_true", help="tiny configuration for plumbing checks (not a valid measurement)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rt = importlib.import_module("raytracer-rust_amd")
+    scenegen = importlib.import_module("raytracer-rust_amd.scenegen")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---------------------------------------------------------------- scene
+    split = args.split or ("tiles" if args.workload == "c4" else "spp")
+    if args.workload == "c3":
+        sc = scenegen.scene_c3(*((320, 180) if args.small else (1920, 1080)))
+        name = "C3 RTIOW ~485 spheres"
+    elif args.workload == "c4":
+        sc = scenegen.scene_c4(*((384, 216, 100, 50) if args.small else (3840, 2160, 1000, 500)))
+        name = "C4 1M-triangle torus + plane"
+    else:
+        sc = scenegen.scene_c5(*((320, 180, 100, 50) if args.small else (1920, 1080, 1000, 500)))
+        name = "C5 ~485 spheres + 1M-triangle torus"
+    W, H = sc["width"], sc["height"]
+    grid_n = 64                                   # jitter:64 -> 4096 cells, SURVEY 8d C5
+    spp = args.spp_per_step
+    t0 = time.time()
+    scene = rt.Scene.from_objects(W, H, sc["background"], sc["camera"], sc["objects"])
+    ctx = rt.Context(local_rank)
+    ctx.upload(scene)
+    upload_s = time.time() - t0
+
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    total = torch.zeros_like(accum)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(k, timing=False, counters=False):
+        """One batch: spp samples/pixel on this rank (or this rank's tiles), reduce, resolve."""
+        if split == "spp":
+            cell0 = ((k * world + rank) * spp) % (grid_n * grid_n)      # disjoint cell ranges per rank and step
+            p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
+                                sample_end=cell0 + spp, timing=timing, counters=counters)
+        else:
+            cell0 = (k * spp) % (grid_n * grid_n)
+            p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
+                                sample_end=cell0 + spp, tile_index=rank, tile_count=world, timing=timing, counters=counters)
+        accum.zero_()
+        ctx.render_accumulate(p, accum, stream.cuda_stream)
+        if world > 1:
+            # the exchange step of the sample split: sum the partial accumulators on rank 0 over xGMI
+            # (tile split: the ranks' tiles are disjoint, the same reduce assembles the frame)
+            total.copy_(accum)
+            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
+            src = total
+        else:
+            src = accum
+        if rank == 0:
+            return ctx.resolve(src, spp * (world if split == "spp" else 1), stream=stream.cuda_stream)
+        return None
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---------------------------------------------------------------- warmup, counters
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    ctx.stats_reset()
+    step(0, counters=True)                                            # untimed: mean nodes / prims per ray
+    cst = ctx.stats()
+    nodes_per_ray = cst["nodes_visited"] / max(1, cst["rays_total"])
+    prims_per_ray = cst["prims_tested"] / max(1, cst["rays_total"])
+    barrier()
+    ctx.stats_reset()
+
+    # ---------------------------------------------------------------- timed region
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, timing=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st["rays_total"]), float(st["paths"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(t_el.item())
+    total_rays, total_paths = float(rays[0].item()), float(rays[1].item())
+
+    if rank == 0:
+        n_planes = len([o for o in sc["objects"] if o["type"] == "Plane"])
+        # algorithmic bytes of one closest-hit query ("k_closest_hit"): 32 B ray words a,b in,
+        # 16 B hit record out, 64 B per BVH node visited, 48 B per primitive tested, 32 B per plane
+        bytes_per_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray + 32.0 * n_planes
+        flops_per_ray = 40.0 * nodes_per_ray + 45.0 * prims_per_ray + 10.0 * n_planes
+        launches = max(1, st["hit_launches"])
+        rays_per_launch = st["rays_total"] / launches
+        ms_per_launch = st["hit_ms"] / launches
+        achieved = rays_per_launch * bytes_per_ray / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        valu = rays_per_launch * flops_per_ray / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc runs)
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and not args.small:
+                    traffic = tj.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (whole node) at 1080p" if args.workload != "c4" else "Mrays/s (whole node) at 4K",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %dx%d, depth %d, %d spp/step/GPU of a jitter:%d grid, %s split%s" %
+                                   (name, W, H, args.depth, spp, grid_n, split, " [SMALL: not a measurement]" if args.small else ""),
+                       "paths_per_step": total_paths / args.steps, "rays_per_path": total_rays / max(1.0, total_paths),
+                       "samples_per_s": total_paths / elapsed, "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"],
+                       "bvh_build_ms": st["bvh_build_ms"], "scene_upload_s": upload_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_closest_hit", "launches": st["hit_launches"], "ms_per_launch": ms_per_launch,
+                         "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
+                         "prims_per_ray": prims_per_ray, "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
+                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(sc, scenegen, args):
+    """The oracle (the reference's own algorithm: linear object scan, brute-force triangles behind
+    one AABB, f64) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    threads = min(os.cpu_count() or 1, 16)        # the GPU box grants 16 cores per GPU
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    step = max(1, args.cpu_sample_step if not args.small else 4)
+    t0 = time.perf_counter()
+    r = osc.render_crop((0, sc["width"], 0, sc["height"]), mode="jitter", N=1, depth=args.depth, seed=7, threads=threads, step=step)
+    dt = time.perf_counter() - t0
+    npx = len(range(0, sc["width"], step)) * len(range(0, sc["height"], step))
+    return {"value": r["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "every %dth pixel and row of the same frame (%d pixels), 1 spp, depth %d: %d rays in %.1f s" %
+                      (step, npx, args.depth, r["rays"], dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,9 @@ def lib():
         L.orc_render.restype = C.c_uint64
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint64, C.c_int, C.c_long, C.c_long, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
+        L.orc_render_crop.restype = C.c_uint64
+        L.orc_render_crop.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint64, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long,
+                                      C.c_long, C.c_void_p]
         L.orc_texture_oob_count.restype = C.c_uint64
         L.orc_vec_dot_cross.argtypes = [C.c_void_p] * 4
         L.orc_vec_normalized.argtypes = [C.c_void_p] * 2
@@ -335,3 +338,12 @@ class OracleScene:
         rays = self.L.orc_render(self.h, 0 if mode == "uniform" else 1, int(N), int(depth), int(seed), int(threads), int(s_begin),
                                  int(s_end), _p(s), _p(c), _p(b))
         return dict(sum=s, color=c, rgb8=b, rays=int(rays))
+
+    def render_crop(self, crop, mode="jitter", N=1, depth=5, seed=1, threads=None, step=1):
+        """Renders only every step-th pixel/row of crop = (x0, x1, row0, row1); returns dict(sum (full frame, zeros outside), rays)."""
+        if threads is None:
+            threads = min(os.cpu_count() or 1, 64)
+        s = np.zeros((self.height, self.width, 3))
+        x0, x1, r0, r1 = crop
+        rays = self.L.orc_render_crop(self.h, 0 if mode == "uniform" else 1, int(N), int(depth), int(seed), int(threads), x0, x1, r0, r1, int(step), _p(s))
+        return dict(sum=s, rays=int(rays))

@@ -583,20 +583,23 @@ static inline uint64_t pixel_seed(uint64_t seed, uint64_t i, uint64_t j) {
 // color_out = mean -> sqrt -> clamp, rgb8_out = to_output.
 template <class R>
 static void render(Scene<R>& sc, int mode, size_t N, int depth, uint64_t seed, int threads, long s_begin, long s_end,
-                   double* sum_out, double* color_out, uint8_t* rgb8_out) {
+                   double* sum_out, double* color_out, uint8_t* rgb8_out, long cx0 = 0, long cx1 = -1, long crow0 = 0, long crow1 = -1, long cstep = 1) {
     const size_t W = sc.width, H = sc.height;
+    // optional crop [cx0,cx1) x [crow0,crow1) in output coordinates, every cstep-th pixel and row
+    // (bounded cpu_baseline samples); outputs keep the full-frame layout
+    if (cx1 < 0) { cx0 = 0; cx1 = (long)W; crow0 = 0; crow1 = (long)H; }
     if (s_begin < 0) s_begin = 0;
     if (s_end < 0 || s_end > (long)(N * N)) s_end = (long)(N * N);
-    std::atomic<size_t> next_row{0};
+    std::atomic<size_t> next_row{(size_t)crow0};
     std::atomic<uint64_t> total_rays{0};
     auto worker = [&]() {
         std::vector<std::pair<double, double>> samples;
         uint64_t nrays = 0;
         for (;;) {
-            size_t row = next_row.fetch_add(1);
-            if (row >= H) break;
+            size_t row = next_row.fetch_add((size_t)cstep);
+            if (row >= (size_t)crow1) break;
             size_t j = H - 1 - row;
-            for (size_t i = 0; i < W; ++i) {
+            for (size_t i = (size_t)cx0; i < (size_t)cx1; i += (size_t)cstep) {
                 Rng g(pixel_seed(seed, i, j));
                 if (mode == 0) uniform_grid_sampling(N, (double)i, (double)j, samples);
                 else jitter_sampling(N, (double)i, (double)j, g, samples);
@@ -795,6 +798,12 @@ uint64_t orc_render(OrcScene* s, int mode, long N, int depth, uint64_t seed, int
                     double* color_out, uint8_t* rgb8_out) {
     if (s->prec == 0) { s->d.rays_traced = 0; render(s->d, mode, (size_t)N, depth, seed, threads, s_begin, s_end, sum_out, color_out, rgb8_out); return s->d.rays_traced.load(); }
     s->f.rays_traced = 0; render(s->f, mode, (size_t)N, depth, seed, threads, s_begin, s_end, sum_out, color_out, rgb8_out); return s->f.rays_traced.load();
+}
+uint64_t orc_render_crop(OrcScene* s, int mode, long N, int depth, uint64_t seed, int threads, long x0, long x1, long row0, long row1,
+                         long step, double* sum_out) {
+    if (step < 1) step = 1;
+    if (s->prec == 0) { s->d.rays_traced = 0; render(s->d, mode, (size_t)N, depth, seed, threads, 0, -1, sum_out, nullptr, nullptr, x0, x1, row0, row1, step); return s->d.rays_traced.load(); }
+    s->f.rays_traced = 0; render(s->f, mode, (size_t)N, depth, seed, threads, 0, -1, sum_out, nullptr, nullptr, x0, x1, row0, row1, step); return s->f.rays_traced.load();
 }
 uint64_t orc_texture_oob_count() { return g_tex_oob.load(); }
 

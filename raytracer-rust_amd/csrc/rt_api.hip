@@ -47,6 +47,7 @@ struct rt_context {
     uint32_t* ctl = nullptr;
     unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 3 words
     uint64_t paths_total = 0;
+    uint64_t rays0_total = 0;   // primary rays actually traced (iteration 0)
 
     // timing of closest-hit launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -405,6 +406,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                     px += (uint64_t)std::min(8u, sc.width - tx * 8) * std::min(8u, sc.height - ty * 8);
                 }
                 ctx->paths_total += px * ns;
+                if (hits_only || p->depth > 0) ctx->rays0_total += px * ns;
             }
             const uint32_t depth = hits_only ? 1u : p->depth;
             const uint32_t iters = depth ? depth + gens : 0u;          // raytrace.rs:52-54: depth 0 traces nothing
@@ -524,6 +526,7 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     if (ctx->stats_dev) {
         std::vector<unsigned long long> h(CTL_MAX_IT + 3);
         HIP_TRY(ctx, hipMemcpy(h.data(), ctx->stats_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        h[0] = ctx->rays0_total;
         for (int i = 0; i < CTL_MAX_IT; ++i) { out->rays_per_iteration[i] = h[i]; out->rays_total += h[i]; }
         out->queue_overflow = h[CTL_MAX_IT];
         out->nodes_visited = h[CTL_MAX_IT + 1];
@@ -546,7 +549,7 @@ int rt_stats_reset(rt_context* ctx) {
     DeviceGuard g(ctx->device);
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (ctx->stats_dev) HIP_TRY(ctx, hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 3) * sizeof(unsigned long long)));
-    ctx->events_used = 0; ctx->hit_ms = 0; ctx->hit_launches = 0; ctx->paths_total = 0;
+    ctx->events_used = 0; ctx->hit_ms = 0; ctx->hit_launches = 0; ctx->paths_total = 0; ctx->rays0_total = 0;
     return 0;
 }
 

@@ -9,6 +9,8 @@ namespace rtamd {
 constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;    // hit code: nothing hit
 constexpr uint32_t HIT_PLANE_BIT = 0x80000000u;  // hit code: plane index in the low bits
 constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primitive
+constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: not a ray
+constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
 
 // control block (uint32 words, zeroed at the start of every pass)

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
         uint32_t x = 0, row = 0;
         const bool valid = slot_to_pixel(sc, pp, pl, x, row);
         radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 A, B, C;
+        // slot == path id: no compaction (one atomic per wave on a single counter costs more than the
+        // whole kernel).  Padding slots of border tiles are flagged and skipped downstream.
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = make_float4(0.f, 0.f, __uint_as_float(SRC_INVALID), __uint_as_float(pid));
+        float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
             const uint32_t s = pp.s_begin + s_local;
             const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
@@ -126,13 +129,11 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
             B = make_float4(d.y, d.z, __uint_as_float(SRC_NONE), __uint_as_float(pid));
             C = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
         }
-        const uint32_t slot = wave_alloc(valid, 1u, &ctl[CTL_QCOUNT + 0]);
-        if (valid && slot < capacity) {
-            q.a[slot] = A;
-            q.b[slot] = B;
-            q.c[slot] = C;
-        }
+        q.a[pid] = A;
+        q.b[pid] = B;
+        q.c[pid] = C;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
 }
 
 // ---------------------------------------------------------------- closest hit
@@ -215,6 +216,8 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
     return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
 
+constexpr uint32_t FETCH_SUB = 8;   // 64-ray chunks fetched per atomic
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
@@ -226,17 +229,24 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
     const float4* __restrict__ prims = sc.prims;
     uint32_t cnt_nodes = 0, cnt_prims = 0;
 
-    for (;;) {
-        // persistent waves: fetch the next 64 rays
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t sub = FETCH_SUB, base = 0;; ++sub) {
+        // persistent waves: fetch the next FETCH_SUB x 64 rays with ONE atomic (a single counter
+        // sustains only ~90 atomics/us chip-wide; per-64-ray fetches made it the bottleneck)
+        if (sub == FETCH_SUB) {
+            if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], 64u * FETCH_SUB);
+            base = __builtin_amdgcn_readfirstlane(base);
+            sub = 0;
+        } else {
+            base += 64u;
+        }
         if (base >= n) break;
         const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 A = q.a[i], B = q.b[i];
+        const float4 B = i < n ? q.b[i] : make_float4(0.f, 0.f, __uint_as_float(SRC_INVALID), 0.f);
+        const uint32_t src = __float_as_uint(B.z);
+        if (i < n && src == SRC_INVALID) hits[i] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);
+        if (i < n && src != SRC_INVALID) {
+            const float4 A = q.a[i];
             const f3 o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
-            const uint32_t src = __float_as_uint(B.z);
             Best best;
             best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
 
@@ -399,17 +409,38 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
     }
 }
 
+// Block-level compaction: every thread of the block must call this (converged).  Threads with
+// `want` get `per_lane` consecutive slots; ONE atomic per 1024-thread block.
+constexpr int SHADE_THREADS = 1024;
+__device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, uint32_t* counter, uint32_t* lds /* [17] */) {
+    const uint64_t m = __ballot(want);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(m) * per_lane;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < SHADE_THREADS / 64; ++w) { const uint32_t c = lds[w]; lds[w] = total; total += c; }
+        lds[16] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = lds[16] + lds[wave] + rank * per_lane;
+    __syncthreads();   // lds is reused by the next call
+    return slot;
+}
+
 // One thread per ray of iteration `it`.  last != 0: this is the last allowed bounce
 // (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const float4* __restrict__ hits, RayQueue qo,
+__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue qi, const float4* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
+    __shared__ uint32_t lds_alloc[17];
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
-    const uint32_t n_pad = (n + 63u) & ~63u;
+    const uint32_t n_pad = (n + (SHADE_THREADS - 1)) & ~(uint32_t)(SHADE_THREADS - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {   // wave-uniform trip count
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {   // block-uniform trip count
         bool emit = false;       // continue with a scattered ray
         bool fire = false;       // spawn shadow rays
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
@@ -421,7 +452,9 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
             thr = mk(C.x, C.y, C.z);
             rng = __float_as_uint(C.w);
             code = __float_as_uint(H.y);
-            if (code == HIT_MISS) {
+            if (code == HIT_INVALID) {
+                // padding slot: not a ray
+            } else if (code == HIT_MISS) {
                 add_radiance(sc, radiance, pid, thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]));   // raytrace.rs:95
             } else {
                 float t = H.x;
@@ -514,7 +547,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
             }
         }
         if (!last) {
-            const uint32_t slot = wave_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1]);
+            const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (emit) {
                 if (slot < capacity) {
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
@@ -526,7 +559,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RayQueue qi, const f
             }
         } else if (sc.n_lights) {
             const uint32_t L = sc.n_lights;
-            const uint32_t slot0 = wave_alloc(fire, L, &ctl[CTL_QCOUNT + it + 1]);
+            const uint32_t slot0 = block_alloc(fire, L, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (fire) {
                 for (uint32_t l = 0; l < L; ++l) {
                     const uint32_t slot = slot0 + l;
@@ -588,7 +621,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     const float4 A = q.a[i], B = q.b[i], H = hits[i];
     const uint32_t pid = __float_as_uint(B.w);
     uint32_t x, row;
-    if (!slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
+    if (__float_as_uint(B.z) == SRC_INVALID || !slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
     const size_t px = (size_t)row * sc.width + x;
     const uint32_t code = __float_as_uint(H.y);
     int32_t o = -1, t = -1;
@@ -626,7 +659,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
 // adds the pass's counters into the persistent 64-bit statistics
 __global__ void k_stats(const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ stats, uint32_t capacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < CTL_MAX_IT) stats[i] += min(ctl[CTL_QCOUNT + i], capacity);
+    if (i > 0 && i < CTL_MAX_IT) stats[i] += min(ctl[CTL_QCOUNT + i], capacity);   // iteration 0: host-side count of valid pixels
     if (i == CTL_MAX_IT) stats[i] += ctl[CTL_OVERFLOW];
     if (i == CTL_MAX_IT + 1) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_NODES_LO]);
     if (i == CTL_MAX_IT + 2) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_PRIMS_LO]);
@@ -652,8 +685,8 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float4* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
-    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 8u, std::max<uint32_t>(1, cdiv(max_rays, 256)));
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 2u, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
