@@ -174,6 +174,19 @@ def test_tile_split_union_is_bit_identical(ctx):
     assert np.array_equal(parts, full)
 
 
+def test_kernel_tile_set_equals_partition_helper(ctx):
+    D = sub("distributed")
+    load_pair("spheres", ctx)
+    for k in range(3):
+        a, _ = ctx.render_image(rt.RenderParams("grid:1", depth=1, seed=4, tile_index=k, tile_count=3))
+        # depth 1: every pixel of the spheres scene sees an emitter, a surface (black) or nothing;
+        # use the primary-ray count instead of the colour: rays of this rank = masked pixels
+        ctx.stats_reset()
+        ctx.render_image(rt.RenderParams("grid:1", depth=1, seed=4, tile_index=k, tile_count=3))
+        assert ctx.stats()["rays_per_iteration"][0] == int(D.tile_mask(500, 500, k, 3).sum())
+        assert not a[~D.tile_mask(500, 500, k, 3)].any()
+
+
 def test_sample_split_is_linear(ctx):
     load_pair("spheres", ctx)
     full, _ = ctx.render_image(rt.RenderParams("jitter:4", depth=5, seed=8))
