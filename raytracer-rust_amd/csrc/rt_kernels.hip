@@ -216,8 +216,14 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
     return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
 
-constexpr uint32_t FETCH_SUB = 8;   // 64-ray chunks fetched per atomic
+constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
+constexpr uint32_t REFILL_IDLE_LANES = 16;       // refill the wave once this many lanes have no ray
 
+// Persistent waves with per-LANE ray replacement.  A wave owns a private range of ray indices
+// (taken from the iteration's cursor with one atomic per range); a lane whose ray is finished
+// takes the next index of the range, so the 64 lanes stay busy although rays need very different
+// numbers of traversal steps (with one ray per lane per round, 25 % of the VALU lanes were active
+// on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU).
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
@@ -228,119 +234,162 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ prims = sc.prims;
     uint32_t cnt_nodes = 0, cnt_prims = 0;
+    // rays per range: large enough that the cursor sees few atomics, small enough to balance the grid
+    const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t chunk = min(2048u, max(64u, (n / (total_waves * 4u)) & ~63u));
 
-    for (uint32_t sub = FETCH_SUB, base = 0;; ++sub) {
-        // persistent waves: fetch the next FETCH_SUB x 64 rays with ONE atomic (a single counter
-        // sustains only ~90 atomics/us chip-wide; per-64-ray fetches made it the bottleneck)
-        if (sub == FETCH_SUB) {
-            if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], 64u * FETCH_SUB);
-            base = __builtin_amdgcn_readfirstlane(base);
-            sub = 0;
-        } else {
-            base += 64u;
-        }
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        const float4 B = i < n ? q.b[i] : make_float4(0.f, 0.f, __uint_as_float(SRC_INVALID), 0.f);
-        const uint32_t src = __float_as_uint(B.z);
-        if (i < n && src == SRC_INVALID) hits[i] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);
-        if (i < n && src != SRC_INVALID) {
-            const float4 A = q.a[i];
-            const f3 o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
-            Best best;
-            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
+    // wave-uniform range state
+    uint32_t cur = 0, cur_end = 0;
+    bool exhausted = false;
+    // per-lane ray state
+    bool active = false;
+    uint32_t ray = 0, src = SRC_NONE, sp = 0;
+    int32_t node = STACK_SENTINEL;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    float idx = 0.f, idy = 0.f, idz = 0.f;
+    Best best;
+    best.t = 0.f; best.code = HIT_MISS; best.gid = 0u; best.a = 0.f; best.b = 0.f;
 
-            // planes: short linear list (they are unbounded).  intersections.rs:82-104
-            for (uint32_t p = 0; p < sc.n_planes; ++p) {
-                const float4 P0 = sc.planes[2 * p], P1 = sc.planes[2 * p + 1];
-                const f3 nrm = mk(P1.x, P1.y, P1.z);
-                const float dn = dot(nrm, d);
-                if (fabsf(dn) < 1e-6f) continue;
-                if (src == (HIT_PLANE_BIT | p)) continue;   // t would be ~0 < 1e-5 in the reference's f64
-                const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
-                if (!(t >= 1e-5f)) continue;
-                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
-            }
-
-            // a ray that starts on a triangle tests that triangle with the reference's own
-            // operation sequence (see tri_hit_ref); the traversal below skips it
-            if (src < sc.n_prims) {
-                const float4 r2 = prims[3 * src + 2];
-                if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                    const float4 r0 = prims[3 * src], r1 = prims[3 * src + 1];
-                    float t, a, b;
-                    if (COUNT) cnt_prims++;
-                    if (tri_hit_ref(o, d, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), t, a, b))
-                        consider(best, t, src, __float_as_uint(r2.y), a, b);
+    for (;;) {
+        // ---------------- refill: idle lanes take the next rays of the wave's range
+        {
+            const uint64_t idle = __ballot(!active);
+            if (idle != 0ull) {
+                if (cur >= cur_end && !exhausted) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) exhausted = true;
+                    else { cur = base; cur_end = min(base + chunk, n); }
                 }
-            }
-
-            if (sc.n_prims) {
-                const float ooeps = 0x1p-80f;
-                const float idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
-                const float idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
-                const float idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
-                int32_t node = 0;        // root is always an inner node
-                uint32_t sp = 0;
-                for (;;) {
-                    if (node >= 0) {
-                        const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
-                        if (COUNT) cnt_nodes++;
-                        // slab tests of both children over [0, best.t]
-                        float ax = (n0.x - o.x) * idx, bx = (n0.y - o.x) * idx;
-                        float ay = (n0.z - o.y) * idy, by = (n0.w - o.y) * idy;
-                        float az = (n2.x - o.z) * idz, bz = (n2.y - o.z) * idz;
-                        const float near0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-                        const float far0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
-                        ax = (n1.x - o.x) * idx; bx = (n1.y - o.x) * idx;
-                        ay = (n1.z - o.y) * idy; by = (n1.w - o.y) * idy;
-                        az = (n2.z - o.z) * idz; bz = (n2.w - o.z) * idz;
-                        const float near1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-                        const float far1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
-                        const bool h0 = near0 <= far0, h1 = near1 <= far1;
-                        const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                        if (h0 && h1) {
-                            const bool first0 = near0 <= near1;
-                            stk[sp * 64u] = (uint32_t)(first0 ? c1 : c0);
-                            sp++;
-                            node = first0 ? c0 : c1;
-                            continue;
-                        }
-                        if (h0) { node = c0; continue; }
-                        if (h1) { node = c1; continue; }
-                    } else {
-                        // leaf: ~node = (first << 3) | (count - 1)
-                        const uint32_t code = (uint32_t)~node;
-                        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-                        for (uint32_t k = 0; k < count; ++k) {
-                            const uint32_t pi = first + k;
-                            const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
-                            if (COUNT) cnt_prims++;
-                            const uint32_t gid = __float_as_uint(r2.y);
-                            if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                                if (pi == src) continue;   // tested above
-                                // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
-                                // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
-                                const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-                                const f3 pv = cross(d, e2);
-                                const float det = dot(e1, pv);
-                                const f3 tv = o - v0;
-                                const f3 qv = cross(tv, e1);
-                                const float inv = 1.0f / det;
-                                const float a = dot(tv, pv) * inv, b = dot(d, qv) * inv, t = dot(e2, qv) * inv;
-                                if (det != 0.f && a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f) consider(best, t, pi, gid, a, b);
+                if (cur < cur_end) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const uint32_t cand = cur + rank;
+                    const bool take = !active && cand < cur_end;
+                    cur = min(cur + (uint32_t)__popcll(idle), cur_end);
+                    if (take) {
+                        ray = cand;
+                        const float4 B = q.b[ray];
+                        src = __float_as_uint(B.z);
+                        if (src == SRC_INVALID) {
+                            hits[ray] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);   // padding slot
+                        } else {
+                            const float4 A = q.a[ray];
+                            o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
+                            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
+                            // planes: short linear list (they are unbounded).  intersections.rs:82-104
+                            for (uint32_t p = 0; p < sc.n_planes; ++p) {
+                                const float4 P0 = sc.planes[2 * p], P1 = sc.planes[2 * p + 1];
+                                const f3 nrm = mk(P1.x, P1.y, P1.z);
+                                const float dn = dot(nrm, d);
+                                if (fabsf(dn) < 1e-6f) continue;
+                                if (src == (HIT_PLANE_BIT | p)) continue;   // t would be ~0 < 1e-5 in the reference's f64
+                                const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
+                                if (!(t >= 1e-5f)) continue;
+                                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
+                            }
+                            // a ray that starts on a triangle tests that triangle with the reference's own
+                            // operation sequence (see tri_hit_ref); the traversal below skips it
+                            if (src < sc.n_prims) {
+                                const float4 r2 = prims[3 * src + 2];
+                                if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                                    const float4 r0 = prims[3 * src], r1 = prims[3 * src + 1];
+                                    float t, a, b;
+                                    if (COUNT) cnt_prims++;
+                                    if (tri_hit_ref(o, d, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), t, a, b))
+                                        consider(best, t, src, __float_as_uint(r2.y), a, b);
+                                }
+                            }
+                            if (sc.n_prims) {
+                                const float ooeps = 0x1p-80f;
+                                idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+                                idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+                                idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+                                stk[0] = (uint32_t)STACK_SENTINEL;
+                                sp = 1;
+                                node = 0;            // root is always an inner node
+                                active = true;
                             } else {
-                                const float t = sphere_hit(r0, r1, o, d, src == pi);
-                                if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
+                                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
                             }
                         }
                     }
-                    if (sp == 0) break;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---------------- traversal steps until enough lanes ran out of work
+        for (;;) {
+            if (active && node >= 0) {
+                const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+                if (COUNT) cnt_nodes++;
+                // slab tests of both children over [0, best.t]
+                float ax = (n0.x - o.x) * idx, bx = (n0.y - o.x) * idx;
+                float ay = (n0.z - o.y) * idy, by = (n0.w - o.y) * idy;
+                float az = (n2.x - o.z) * idz, bz = (n2.y - o.z) * idz;
+                const float near0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+                const float far0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
+                ax = (n1.x - o.x) * idx; bx = (n1.y - o.x) * idx;
+                ay = (n1.z - o.y) * idy; by = (n1.w - o.y) * idy;
+                az = (n2.z - o.z) * idz; bz = (n2.w - o.z) * idz;
+                const float near1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+                const float far1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
+                const bool h0 = near0 <= far0, h1 = near1 <= far1;
+                const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    const bool first0 = near0 <= near1;
+                    stk[sp * 64u] = (uint32_t)(first0 ? c1 : c0);
+                    sp++;
+                    node = first0 ? c0 : c1;
+                } else if (h0) {
+                    node = c0;
+                } else if (h1) {
+                    node = c1;
+                } else {
                     sp--;
                     node = (int32_t)stk[sp * 64u];
                 }
             }
-            hits[i] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+            if (active && node < 0) {
+                // leaf: ~node = (first << 3) | (count - 1)
+                const uint32_t code = (uint32_t)~node;
+                const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t pi = first + k;
+                    const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
+                    if (COUNT) cnt_prims++;
+                    const uint32_t gid = __float_as_uint(r2.y);
+                    if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                        if (pi == src) continue;   // tested at refill
+                        // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
+                        // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
+                        const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                        const f3 pv = cross(d, e2);
+                        const float det = dot(e1, pv);
+                        const f3 tv = o - v0;
+                        const f3 qv = cross(tv, e1);
+                        const float inv = 1.0f / det;
+                        const float a = dot(tv, pv) * inv, b = dot(d, qv) * inv, t = dot(e2, qv) * inv;
+                        if (det != 0.f && a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f) consider(best, t, pi, gid, a, b);
+                    } else {
+                        const float t = sphere_hit(r0, r1, o, d, src == pi);
+                        if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
+                    }
+                }
+                sp--;
+                node = (int32_t)stk[sp * 64u];
+            }
+            if (active && node == STACK_SENTINEL) {
+                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+                active = false;
+            }
+            const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+            if (n_active == 0u) break;
+            if (!(exhausted && cur >= cur_end) && n_active <= 64u - REFILL_IDLE_LANES) break;   // go and refill
         }
     }
     if (COUNT) {
