@@ -135,17 +135,42 @@ struct Builder {
     }
 };
 
-void set_child_box(GpuNode& g, int which, const Box& b) {
-    // pad by a few ulps of the largest coordinate magnitude / extent so that the f32 slab
-    // test never culls a primitive the exact test would reach
-    float m = 0.f;
-    for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
-    float e = 4e-6f * m + 1e-30f;
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) { lo[k] = b.mn[k] - e; hi[k] = b.mx[k] + e; }
-    if (which == 0) { g.n0[0] = lo[0]; g.n0[1] = hi[0]; g.n0[2] = lo[1]; g.n0[3] = hi[1]; g.n2[0] = lo[2]; g.n2[1] = hi[2]; }
-    else { g.n1[0] = lo[0]; g.n1[1] = hi[0]; g.n1[2] = lo[1]; g.n1[3] = hi[1]; g.n2[2] = lo[2]; g.n2[3] = hi[2]; }
+// Quantises the child boxes of one wide node (see bvh.h).
+void encode_node(GpuNode& g, const Box& node_box, const Box* child_boxes, const int32_t* child_codes, int n_children) {
+    std::memset(&g, 0, sizeof(g));
+    uint32_t e8[3];
+    double scale[3];
+    for (int k = 0; k < 3; ++k) {
+        g.p[k] = node_box.mn[k];
+        double ext = (double)node_box.mx[k] - (double)g.p[k];
+        if (!(ext > 0.0)) ext = 0.0;
+        // smallest power of two s with 255 * s >= ext
+        int e = (ext > 0.0) ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+        while (e < 127 && std::ldexp(255.0, e) < ext) e++;
+        e = std::min(127, std::max(-126, e));
+        e8[k] = (uint32_t)(e + 127);
+        scale[k] = std::ldexp(1.0, e);
+    }
+    g.exps = e8[0] | (e8[1] << 8) | (e8[2] << 16);
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        g.child[i] = i < n_children ? child_codes[i] : CHILD_EMPTY;
+        for (int k = 0; k < 3; ++k) {
+            uint32_t lo = 255, hi = 0;   // empty child: inverted (and masked by CHILD_EMPTY in the kernel)
+            if (i < n_children) {
+                double l = std::floor(((double)child_boxes[i].mn[k] - (double)g.p[k]) / scale[k]);
+                double h = std::ceil(((double)child_boxes[i].mx[k] - (double)g.p[k]) / scale[k]);
+                lo = (uint32_t)std::min(255.0, std::max(0.0, l));
+                hi = (uint32_t)std::min(255.0, std::max(0.0, h));
+            }
+            qlo[k] |= lo << (8 * i);
+            qhi[k] |= hi << (8 * i);
+        }
+    }
+    g.qlo[0] = qlo[0]; g.qlo[1] = qlo[1]; g.qlo[2] = qlo[2];
+    g.qhi_x = qhi[0]; g.qhi_y = qhi[1]; g.qhi_z = qhi[2];
 }
+
 }  // namespace
 
 void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
@@ -225,48 +250,52 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
         }
     }
 
-    // flatten: one GpuNode per inner TmpNode, depth-first so that siblings' subtrees are contiguous
-    std::vector<int32_t> gpu_index(tmp.size(), -1);
-    struct Item { int32_t node; uint32_t depth; };
-    std::vector<Item> st;
+    // collapse the binary tree to 4-wide nodes and flatten depth-first.  A wide node adopts the
+    // children of its binary child with the largest surface area until it has four children.
     auto leaf_code = [&](const TmpNode& t) { return ~(int32_t)((t.first << 3) | (t.count - 1)); };
-    if (tmp[0].left < 0) {
-        // single leaf: synthesise a root over two half leaves (n == 1: the same leaf twice,
-        // which is harmless because a tie with the same scan rank never replaces the hit)
-        GpuNode g; std::memset(&g, 0, sizeof(g));
-        const TmpNode& t = tmp[0];
-        uint32_t h = t.count >= 2 ? t.count / 2 : t.count;
-        TmpNode a = t, b = t;
-        a.count = h;
-        if (t.count >= 2) { b.first = t.first + h; b.count = t.count - h; }
-        a.box.reset(); b.box.reset();
-        for (uint32_t i = 0; i < a.count; ++i) a.box.grow(boxes[out.order[a.first + i]].mn, boxes[out.order[a.first + i]].mx);
-        for (uint32_t i = 0; i < b.count; ++i) b.box.grow(boxes[out.order[b.first + i]].mn, boxes[out.order[b.first + i]].mx);
-        set_child_box(g, 0, a.box); g.child0 = leaf_code(a);
-        set_child_box(g, 1, b.box); g.child1 = leaf_code(b);
-        out.nodes.push_back(g); out.max_depth = 1;
-    } else {
-        st.push_back({0, 1});
-        // first pass assigns indices in DFS order
-        std::vector<int32_t> dfs;
-        while (!st.empty()) {
-            Item it = st.back(); st.pop_back();
-            gpu_index[it.node] = (int32_t)dfs.size(); dfs.push_back(it.node);
-            out.max_depth = std::max(out.max_depth, it.depth);
-            const TmpNode& t = tmp[it.node];
-            if (tmp[t.right].left >= 0) st.push_back({t.right, it.depth + 1});
-            if (tmp[t.left].left >= 0) st.push_back({t.left, it.depth + 1});
+    struct Wide { int32_t tmp; int32_t kids[4]; int n; };
+    auto gather = [&](int32_t x) {
+        Wide w; w.tmp = x; w.n = 0;
+        if (tmp[x].left < 0) { w.kids[w.n++] = x; return w; }      // a lone leaf: one child
+        w.kids[w.n++] = tmp[x].left; w.kids[w.n++] = tmp[x].right;
+        while (w.n < 4) {
+            int best = -1; float area = -1.f;
+            for (int i = 0; i < w.n; ++i)
+                if (tmp[w.kids[i]].left >= 0 && tmp[w.kids[i]].box.half_area() > area) { area = tmp[w.kids[i]].box.half_area(); best = i; }
+            if (best < 0) break;
+            int32_t c = w.kids[best];
+            w.kids[best] = tmp[c].left; w.kids[w.n++] = tmp[c].right;
         }
-        out.nodes.resize(dfs.size());
-        for (size_t k = 0; k < dfs.size(); ++k) {
-            const TmpNode& t = tmp[dfs[k]];
-            GpuNode g; std::memset(&g, 0, sizeof(g));
-            const TmpNode& l = tmp[t.left]; const TmpNode& r = tmp[t.right];
-            set_child_box(g, 0, l.box); set_child_box(g, 1, r.box);
-            g.child0 = l.left >= 0 ? gpu_index[t.left] : leaf_code(l);
-            g.child1 = r.left >= 0 ? gpu_index[t.right] : leaf_code(r);
-            out.nodes[k] = g;
+        return w;
+    };
+    struct Item { int32_t tmp; int32_t gpu; uint32_t depth; uint32_t pending; };
+    std::vector<Item> st;
+    out.nodes.clear();
+    out.nodes.emplace_back();
+    st.push_back({0, 0, 1, 1});   // pending starts at 1: the stack sentinel
+    out.max_stack = 1;
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        Wide w = gather(it.tmp);
+        out.max_depth = std::max(out.max_depth, it.depth);
+        // while a child of this node is traversed, up to n-1 siblings wait on the stack
+        const uint32_t pending = it.pending + (uint32_t)(w.n - 1);
+        out.max_stack = std::max(out.max_stack, pending);
+        Box cb[4]; int32_t codes[4];
+        for (int i = 0; i < w.n; ++i) {
+            const TmpNode& c = tmp[w.kids[i]];
+            cb[i] = c.box;
+            if (c.left >= 0) {
+                codes[i] = (int32_t)out.nodes.size();
+                out.nodes.emplace_back();
+                st.push_back({w.kids[i], codes[i], it.depth + 1, pending});
+            } else {
+                codes[i] = leaf_code(c);
+            }
         }
+        GpuNode g;
+        encode_node(g, tmp[it.tmp].box, cb, codes, w.n);
+        out.nodes[(size_t)it.gpu] = g;
     }
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -260,16 +260,35 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         // the kernel tests A + a*e1 + b*e2 with e1 = fl(B-A), e2 = fl(C-A): one more ulp of slack
         for (int k = 0; k < 3; ++k) { b.mn[k] = next_down(b.mn[k]); b.mx[k] = next_up(b.mx[k]); }
     }
+    // Spheres that dwarf the rest of the scene (RTIOW's radius-1000 ground) stay out of the BVH: their
+    // boxes enclose everything, and they are tested once per ray in full f64 beside the planes.
+    std::vector<uint32_t> bvh_src, big_src;
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        auto grow = [&](const double* p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } };
+        for (uint32_t i = 0; i < d->n_spheres; ++i) grow(&d->sphere_center[3 * i]);
+        for (uint64_t i = 0; i < d->n_triangles * 3; ++i) grow(&d->tri_vertices[3 * i]);
+        double diag = 0;
+        for (int k = 0; k < 3; ++k) if (hi[k] > lo[k]) diag += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+        diag = std::sqrt(diag);
+        for (uint32_t i = 0; i < d->n_spheres; ++i) {
+            const bool big = d->n_spheres + d->n_triangles > 1 && std::fabs(d->sphere_radius[i]) > 0.25 * diag && big_src.size() < 8;
+            (big ? big_src : bvh_src).push_back(i);
+        }
+        for (uint64_t i = 0; i < d->n_triangles; ++i) bvh_src.push_back((uint32_t)(d->n_spheres + i));
+    }
+    std::vector<PrimBox> bvh_boxes(bvh_src.size());
+    for (size_t i = 0; i < bvh_src.size(); ++i) bvh_boxes[i] = boxes[bvh_src[i]];
     Bvh bvh;
-    build_bvh(boxes, bvh);
-    if (bvh.max_depth + 1 > 96) return fail(ctx, "BVH too deep (%u) for the LDS traversal stack", bvh.max_depth);
+    build_bvh(bvh_boxes, bvh);
+    const uint32_t n_leaf_prims = (uint32_t)bvh_src.size();
 
-    // ---- leaf-ordered records
+    // ---- records: BVH primitives in leaf order, then the big spheres
     std::vector<float4> prims((size_t)n_prims * 3);
     std::vector<int4> meta(n_prims);
     std::vector<float> uvs;
     for (uint32_t k = 0; k < n_prims; ++k) {
-        uint32_t src = bvh.order[k];
+        uint32_t src = k < n_leaf_prims ? bvh_src[bvh.order[k]] : big_src[k - n_leaf_prims];
         float4* r = &prims[(size_t)k * 3];
         if (src < d->n_spheres) {
             double v[4] = {d->sphere_center[3 * src], d->sphere_center[3 * src + 1], d->sphere_center[3 * src + 2], d->sphere_radius[src]};
@@ -338,6 +357,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         return 1;
     }
     sc.n_prims = n_prims;
+    sc.n_leaf_prims = n_leaf_prims;
     sc.n_nodes = (uint32_t)bvh.nodes.size();
     sc.n_planes = d->n_planes;
     sc.n_lights = d->n_lights;
@@ -349,7 +369,16 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         sc.vt[k] = d->cam_vertical[k];
     }
     sc.width = d->width; sc.height = d->height;
-    sc.stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2);
+    sc.stack_depth = std::max<uint32_t>(bvh.max_stack, 2);
+    sc.spill_levels = sc.stack_depth > LDS_STACK ? sc.stack_depth - LDS_STACK : 0;
+    {   // overflow area of the LDS traversal stacks: one slice per persistent closest-hit wave
+        const size_t waves = (size_t)ctx->cfg.n_cu * HIT_BLOCKS_PER_CU * 4;
+        const size_t bytes = std::max<size_t>(16, waves * 64 * sc.spill_levels * sizeof(uint32_t));
+        void* sp = nullptr;
+        HIP_TRY(ctx, hipMalloc(&sp, bytes));
+        ctx->scene_allocs.push_back(sp);
+        sc.spill = reinterpret_cast<uint32_t*>(sp);
+    }
     ctx->sc = sc;
     ctx->bvh_nodes = sc.n_nodes; ctx->bvh_depth = bvh.max_depth; ctx->bvh_prims = n_prims; ctx->bvh_build_ms = bvh.build_ms;
     ctx->have_scene = true;

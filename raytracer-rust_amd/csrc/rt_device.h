@@ -12,6 +12,9 @@ constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primiti
 constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: not a ray
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
+constexpr int32_t CHILD_EMPTY_CODE = (int32_t)0x80000000;   // == bvh.h CHILD_EMPTY
+constexpr uint32_t LDS_STACK = 16;            // traversal-stack entries per lane kept in LDS (4 KB per wave)
+constexpr uint32_t HIT_BLOCKS_PER_CU = 8;     // persistent closest-hit blocks (256 threads) per CU
 
 // control block (uint32 words, zeroed at the start of every pass)
 constexpr int CTL_MAX_IT = 320;               // == RT_MAX_ITERATIONS
@@ -43,11 +46,12 @@ struct RayQueue {
 //
 // meta (int4 per primitive, leaf order): (object index, triangle index or -1, material, uv offset or -1)
 struct DevScene {
-    const float4* nodes;      // 4 x float4 per node (bvh.h)
+    const float4* nodes;      // 4 x 16 bytes per 4-wide quantised node (bvh.h)
     const float4* prims;      // 3 x float4 per primitive
     const int4* meta;
     const float* uvs;         // 6 floats per primitive that has uv: (u0,v0,u1,v1,u2,v2)
-    uint32_t n_prims;
+    uint32_t n_prims;         // all primitive records
+    uint32_t n_leaf_prims;    // records [0, n_leaf_prims) are referenced by BVH leaves; the rest are big spheres
     uint32_t n_nodes;
     const float4* planes;     // 2 x float4 per plane: (c.xyz, bits(gid)), (n.xyz, bits(material))
     const int32_t* plane_object;
@@ -63,7 +67,9 @@ struct DevScene {
     // an f32 camera loses 1e-4 relative in t on grazing rays
     double lle[3], hz[3], vt[3];          // lle = lower_left - eye
     uint32_t width, height;
-    uint32_t stack_depth;     // LDS traversal-stack entries per lane
+    uint32_t stack_depth;     // traversal-stack entries a lane can need (bvh.h max_stack)
+    uint32_t* spill;          // global overflow of the LDS stacks: [wave][level - LDS_STACK][lane]
+    uint32_t spill_levels;    // max(0, stack_depth - LDS_STACK)
 };
 
 struct PassParams {

@@ -9,6 +9,8 @@
 // (file:line are relative to /root/reference/src/raytracer/.)
 #include "rt_kernels.h"
 
+#include <cstdlib>
+
 namespace rtamd {
 namespace {
 
@@ -152,31 +154,55 @@ __device__ __forceinline__ void consider(Best& best, float t, uint32_t code, uin
     }
 }
 
-// intersections.rs:40-80 in f64 (the reference's own number type): the f32 form of
-// c = |oc|^2 - r^2 cancels catastrophically for the large spheres the scenes use
-// (radius 1000 ground, radius 100 light at distance 866).  from_self: the ray starts
-// on this very sphere, so one root is 0 (rejected by the reference's t > 1e-5) and the
-// other is -b/a exactly.
-__device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
+// intersections.rs:40-80.  The f32 form of c = |oc|^2 - r^2 cancels catastrophically for the large
+// spheres the scenes use (radius 1000 ground, radius 100 light at distance 866), so oc, a, b/2, c and
+// the discriminant are formed in f64 (the reference's own number type; a dozen half-rate FMAs).
+// from_self: the ray starts on this very sphere, so one root is 0 (rejected by the reference's
+// t > 1e-5) and the other is -b/a exactly.
+struct SphereQ {
+    double a, hb, disc;   // a = d.d, hb = d.oc (= b/2), disc = hb^2 - a*c
+};
+__device__ __forceinline__ SphereQ sphere_quadratic(const float4 r0, const float4 r1, f3 o, f3 d) {
     const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
     const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
     const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
     const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
     const double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
     const double dx = d.x, dy = d.y, dz = d.z;
-    const double a = dx * dx + dy * dy + dz * dz;
-    const double hb = dx * ocx + dy * ocy + dz * ocz;   // b/2
+    SphereQ q;
+    q.a = dx * dx + dy * dy + dz * dz;
+    q.hb = dx * ocx + dy * ocy + dz * ocz;
+    q.disc = q.hb * q.hb - q.a * (ocx * ocx + ocy * ocy + ocz * ocz - rad * rad);
+    return q;
+}
+// Full f64 roots: big spheres (tested once per ray, all lanes together).
+__device__ __forceinline__ float sphere_hit64(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
+    const SphereQ q = sphere_quadratic(r0, r1, o, d);
     if (from_self) {
-        const double t = -2.0 * hb / a;
+        const double t = -2.0 * q.hb / q.a;
         return t > 1e-5 ? (float)t : -1.f;
     }
-    const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
-    const double disc = hb * hb - a * c;
-    if (!(disc >= 0.0)) return -1.f;
-    const double sq = sqrt(disc);
-    const double t1 = (-hb - sq) / a, t2 = (-hb + sq) / a;
+    if (!(q.disc >= 0.0)) return -1.f;
+    const double sq = sqrt(q.disc);
+    const double t1 = (-q.hb - sq) / q.a, t2 = (-q.hb + sq) / q.a;
     if (t1 > 1e-5) return (float)t1;
     if (t2 > 1e-5) return (float)t2;
+    return -1.f;
+}
+// Spheres inside BVH leaves: f64 discriminant, then f32 square root and division (the cancellation
+// is in the discriminant; sqrt/div in f64 cost ~100 instructions for the whole wave).
+__device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
+    const SphereQ q = sphere_quadratic(r0, r1, o, d);
+    const float ia = 1.0f / (float)q.a;
+    if (from_self) {
+        const float t = (float)(-2.0 * q.hb) * ia;
+        return t > 1e-5f ? t : -1.f;
+    }
+    if (!(q.disc >= 0.0)) return -1.f;
+    const double sq = (double)sqrtf((float)q.disc);
+    const float t1 = (float)(-q.hb - sq) * ia, t2 = (float)(-q.hb + sq) * ia;
+    if (t1 > 1e-5f) return t1;
+    if (t2 > 1e-5f) return t2;
     return -1.f;
 }
 
@@ -216,6 +242,7 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
     return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
 
+constexpr int32_t STEP_KEEP = 0x7FFFFFFE;        // traversal step result: stay in the current leaf
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
 constexpr uint32_t REFILL_IDLE_LANES = 16;       // refill the wave once this many lanes have no ray
 
@@ -224,12 +251,28 @@ constexpr uint32_t REFILL_IDLE_LANES = 16;       // refill the wave once this ma
 // takes the next index of the range, so the 64 lanes stay busy although rays need very different
 // numbers of traversal steps (with one ray per lane per round, 25 % of the VALU lanes were active
 // on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU).
+#ifndef RT_HIT_MIN_WAVES
+#define RT_HIT_MIN_WAVES 1   // min waves per SIMD the register allocator must allow (tuning)
+#endif
+
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
+__global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
-    extern __shared__ uint32_t lds_stack[];   // [wave][level][lane]: conflict-free per-lane stacks
+    // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
+    // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
+    __shared__ uint32_t lds_stack[4 * LDS_STACK * 64];
     const uint32_t lane = lane_id();
-    uint32_t* const stk = lds_stack + (threadIdx.x >> 6) * (sc.stack_depth * 64u) + lane;
+    uint32_t* const stk = lds_stack + (threadIdx.x >> 6) * (LDS_STACK * 64u) + lane;
+    uint32_t* const spill = sc.spill + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * sc.spill_levels) * 64u + lane;
+    auto push = [&](uint32_t& sp_, uint32_t v) {
+        if (sp_ < LDS_STACK) stk[sp_ * 64u] = v;
+        else spill[(size_t)(sp_ - LDS_STACK) * 64u] = v;
+        sp_++;
+    };
+    auto pop = [&](uint32_t& sp_) -> int32_t {
+        sp_--;
+        return (int32_t)(sp_ < LDS_STACK ? stk[sp_ * 64u] : spill[(size_t)(sp_ - LDS_STACK) * 64u]);
+    };
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ prims = sc.prims;
@@ -244,6 +287,7 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
     // per-lane ray state
     bool active = false;
     uint32_t ray = 0, src = SRC_NONE, sp = 0;
+    uint32_t pcur = 0, pend = 0;   // primitives of the leaf the lane is in (pcur < pend: leaf mode)
     int32_t node = STACK_SENTINEL;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     float idx = 0.f, idy = 0.f, idz = 0.f;
@@ -288,9 +332,16 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
                                 if (!(t >= 1e-5f)) continue;
                                 consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
                             }
+                            // big spheres (kept out of the BVH), full f64
+                            for (uint32_t pi = sc.n_leaf_prims; pi < sc.n_prims; ++pi) {
+                                const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
+                                if (COUNT) cnt_prims++;
+                                const float t = sphere_hit64(r0, r1, o, d, src == pi);
+                                if (t > 0.f) consider(best, t, pi, __float_as_uint(r2.y), 0.f, 0.f);
+                            }
                             // a ray that starts on a triangle tests that triangle with the reference's own
                             // operation sequence (see tri_hit_ref); the traversal below skips it
-                            if (src < sc.n_prims) {
+                            if (src < sc.n_leaf_prims) {
                                 const float4 r2 = prims[3 * src + 2];
                                 if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
                                     const float4 r0 = prims[3 * src], r1 = prims[3 * src + 1];
@@ -300,7 +351,7 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
                                         consider(best, t, src, __float_as_uint(r2.y), a, b);
                                 }
                             }
-                            if (sc.n_prims) {
+                            if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
                                 idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
                                 idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
@@ -308,6 +359,7 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
                                 stk[0] = (uint32_t)STACK_SENTINEL;
                                 sp = 1;
                                 node = 0;            // root is always an inner node
+                                pcur = pend = 0;
                                 active = true;
                             } else {
                                 hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
@@ -322,70 +374,119 @@ __global__ __launch_bounds__(256) void k_closest_hit(DevScene sc, RayQueue q, fl
             continue;
         }
 
-        // ---------------- traversal steps until enough lanes ran out of work
+        // ---------------- traversal steps until enough lanes ran out of work.
+        // Every step is ONE memory round trip for every lane: a lane is either at an inner node
+        // (four 16-byte words) or at one primitive of a leaf (three words); both kinds of loads are
+        // issued together before either result is used.
         for (;;) {
-            if (active && node >= 0) {
-                const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+            const bool leafm = active && pcur < pend;
+            const bool nodem = active && !leafm;
+            float4 L0 = make_float4(0.f, 0.f, 0.f, 0.f), L1 = L0, L2 = L0, L3 = L0;
+            if (active) {
+                const float4* __restrict__ base = leafm ? prims + 3 * (size_t)pcur : nodes + 4 * (size_t)node;
+                L0 = base[0]; L1 = base[1]; L2 = base[2];
+                if (nodem) L3 = base[3];
+            }
+            int32_t nxt = STEP_KEEP;
+            if (nodem) {
+                // 4-wide node, 8-bit child boxes relative to (p, 2^e) -- bvh.h
                 if (COUNT) cnt_nodes++;
-                // slab tests of both children over [0, best.t]
-                float ax = (n0.x - o.x) * idx, bx = (n0.y - o.x) * idx;
-                float ay = (n0.z - o.y) * idy, by = (n0.w - o.y) * idy;
-                float az = (n2.x - o.z) * idz, bz = (n2.y - o.z) * idz;
-                const float near0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-                const float far0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
-                ax = (n1.x - o.x) * idx; bx = (n1.y - o.x) * idx;
-                ay = (n1.z - o.y) * idy; by = (n1.w - o.y) * idy;
-                az = (n2.z - o.z) * idz; bz = (n2.w - o.z) * idz;
-                const float near1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-                const float far1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t)) * 1.0000004f;
-                const bool h0 = near0 <= far0, h1 = near1 <= far1;
-                const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    const bool first0 = near0 <= near1;
-                    stk[sp * 64u] = (uint32_t)(first0 ? c1 : c0);
-                    sp++;
-                    node = first0 ? c0 : c1;
-                } else if (h0) {
-                    node = c0;
-                } else if (h1) {
-                    node = c1;
+                const uint32_t ex = __float_as_uint(L0.w);
+                const float sx = __uint_as_float((ex & 0xFFu) << 23), sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23),
+                            sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
+                const float pox = L0.x - o.x, poy = L0.y - o.y, poz = L0.z - o.z;
+                // plane distance t = q * (s * idir) + (p - o) * idir: s is a power of two, so s * idir and
+                // q * (s * idir) are exact and one FMA per plane carries two roundings in all
+                const float sxi = sx * idx, syi = sy * idy, szi = sz * idz;
+                const float bxi = pox * idx, byi = poy * idy, bzi = poz * idz;
+                // bound of the rounding error of those distances
+                const float eps = 0x1p-22f * fmaxf(fmaxf((fabsf(pox) + 256.f * sx) * fabsf(idx), (fabsf(poy) + 256.f * sy) * fabsf(idy)),
+                                                   (fabsf(poz) + 256.f * sz) * fabsf(idz));
+                // entry / exit planes by the sign of the ray direction
+                const uint32_t qlx = __float_as_uint(L2.x), qly = __float_as_uint(L2.y), qlz = __float_as_uint(L2.z);
+                const uint32_t qhx = __float_as_uint(L2.w), qhy = __float_as_uint(L3.x), qhz = __float_as_uint(L3.y);
+                const uint32_t enx = idx >= 0.f ? qlx : qhx, exx = idx >= 0.f ? qhx : qlx;
+                const uint32_t eny = idy >= 0.f ? qly : qhy, exy = idy >= 0.f ? qhy : qly;
+                const uint32_t enz = idz >= 0.f ? qlz : qhz, exz = idz >= 0.f ? qhz : qlz;
+                uint32_t key[4];
+                int32_t cc[4] = {__float_as_int(L1.x), __float_as_int(L1.y), __float_as_int(L1.z), __float_as_int(L1.w)};
+                uint32_t nhit = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float tnx = fmaf((float)((enx >> (8 * c)) & 0xFFu), sxi, bxi);
+                    const float tny = fmaf((float)((eny >> (8 * c)) & 0xFFu), syi, byi);
+                    const float tnz = fmaf((float)((enz >> (8 * c)) & 0xFFu), szi, bzi);
+                    const float tfx = fmaf((float)((exx >> (8 * c)) & 0xFFu), sxi, bxi);
+                    const float tfy = fmaf((float)((exy >> (8 * c)) & 0xFFu), syi, byi);
+                    const float tfz = fmaf((float)((exz >> (8 * c)) & 0xFFu), szi, bzi);
+                    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz) - eps, 0.f);
+                    const float tf = fminf(fminf(fminf(tfx, tfy), tfz) + eps, best.t);
+                    const bool h = tn <= tf && cc[c] != CHILD_EMPTY_CODE;
+                    nhit += h ? 1u : 0u;
+                    // sortable key: distance bits (non-negative float == monotonic uint) with the slot in the low bits
+                    key[c] = h ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)c) : 0xFFFFFFFFu;
+                }
+                // sort the four (key, child) pairs by distance: 5-comparator network
+#define RT_CSWAP(a, b)                                                   \
+    {                                                                    \
+        const bool sw = key[b] < key[a];                                 \
+        const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
+        const int32_t ca = sw ? cc[b] : cc[a], cb = sw ? cc[a] : cc[b];   \
+        key[a] = ka; key[b] = kb; cc[a] = ca; cc[b] = cb;                \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                if (nhit == 0u) {
+                    nxt = pop(sp);
                 } else {
-                    sp--;
-                    node = (int32_t)stk[sp * 64u];
+                    // nearest child next; the others wait on the stack, nearest of them on top
+                    if (nhit > 3u) push(sp, (uint32_t)cc[3]);
+                    if (nhit > 2u) push(sp, (uint32_t)cc[2]);
+                    if (nhit > 1u) push(sp, (uint32_t)cc[1]);
+                    nxt = cc[0];
                 }
             }
-            if (active && node < 0) {
-                // leaf: ~node = (first << 3) | (count - 1)
-                const uint32_t code = (uint32_t)~node;
-                const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t pi = first + k;
-                    const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
-                    if (COUNT) cnt_prims++;
-                    const uint32_t gid = __float_as_uint(r2.y);
-                    if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                        if (pi == src) continue;   // tested at refill
+            if (leafm) {
+                if (COUNT) cnt_prims++;
+                const uint32_t pi = pcur;
+                const uint32_t gid = __float_as_uint(L2.y);
+                if (__float_as_uint(L2.z) == PRIM_TRIANGLE) {
+                    if (pi != src) {   // the src triangle was tested at refill
                         // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
                         // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
-                        const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                        const f3 v0 = mk(L0.x, L0.y, L0.z), e1 = mk(L0.w, L1.x, L1.y), e2 = mk(L1.z, L1.w, L2.x);
                         const f3 pv = cross(d, e2);
                         const float det = dot(e1, pv);
                         const f3 tv = o - v0;
                         const f3 qv = cross(tv, e1);
-                        const float inv = 1.0f / det;
-                        const float a = dot(tv, pv) * inv, b = dot(d, qv) * inv, t = dot(e2, qv) * inv;
-                        if (det != 0.f && a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f) consider(best, t, pi, gid, a, b);
-                    } else {
-                        const float t = sphere_hit(r0, r1, o, d, src == pi);
-                        if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
+                        // numerators of a, b, t with the sign of det folded in: the four reject tests
+                        // need no division (a < 0 <=> ua*sgn(det) < 0, a + b > 1 <=> ua + ub > |det|)
+                        const float sg = det < 0.f ? -1.f : 1.f;
+                        const float ua = dot(tv, pv) * sg, ub = dot(d, qv) * sg, ut = dot(e2, qv) * sg, ad = fabsf(det);
+                        if (ad > 0.f && ua >= 0.f && ub >= 0.f && ua + ub <= ad && ut >= 0.f) {
+                            const float inv = 1.0f / ad;
+                            consider(best, ut * inv, pi, gid, ua * inv, ub * inv);
+                        }
                     }
+                } else {
+                    const float t = sphere_hit(L0, L1, o, d, src == pi);
+                    if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
                 }
-                sp--;
-                node = (int32_t)stk[sp * 64u];
+                pcur++;
+                if (pcur == pend) nxt = pop(sp);
             }
-            if (active && node == STACK_SENTINEL) {
-                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
-                active = false;
+            if (nxt != STEP_KEEP) {
+                if (nxt == STACK_SENTINEL) {
+                    hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+                    active = false;
+                } else if (nxt >= 0) {
+                    node = nxt;
+                } else {
+                    // leaf: ~nxt = (first << 3) | (count - 1)
+                    const uint32_t code = (uint32_t)~nxt;
+                    pcur = code >> 3;
+                    pend = pcur + (code & 7u) + 1u;
+                }
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             if (n_active == 0u) break;
@@ -726,9 +827,10 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
 }
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float4* hits, uint32_t* ctl, int it, uint32_t capacity,
                         uint32_t max_rays, bool counters, hipStream_t st) {
-    const size_t lds = (size_t)4 * 64 * sc.stack_depth * sizeof(uint32_t);
-    uint32_t per_cu = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    uint32_t per_cu = HIT_BLOCKS_PER_CU;
+    if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
+    const size_t lds = 0;
     if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
     else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
 }

@@ -59,7 +59,8 @@ ABI_SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "librtamd.so")
+    # RTAMD_LIB: alternative build of the library (tuning experiments)
+    return os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "librtamd.so")
 
 
 def load_library():
