@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -12,7 +13,7 @@ namespace rtamd {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kMaxLeaf = 4;        // primitives per leaf (the leaf encoding allows 8)
+static uint32_t kMaxLeaf = 2;           // primitives per leaf (the leaf encoding allows 8)
 constexpr uint32_t kMedianDepth = 40;   // beyond this depth fall back to median splits (bounds the depth)
 
 struct Box {
@@ -180,6 +181,7 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
     for (uint32_t i = 0; i < n; ++i) out.order[i] = i;
     if (n == 0) { out.build_ms = 0; return; }
 
+    if (const char* e = getenv("RTAMD_MAX_LEAF")) kMaxLeaf = (uint32_t)std::min(8, std::max(1, atoi(e)));   // tuning experiments only
     Builder B(boxes, out.order);
     std::vector<TmpNode> tmp;
     if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));

@@ -244,7 +244,10 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
 
 constexpr int32_t STEP_KEEP = 0x7FFFFFFE;        // traversal step result: stay in the current leaf
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
-constexpr uint32_t REFILL_IDLE_LANES = 16;       // refill the wave once this many lanes have no ray
+#ifndef RT_REFILL
+#define RT_REFILL 16
+#endif
+constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this many lanes have no ray
 
 // Persistent waves with per-LANE ray replacement.  A wave owns a private range of ray indices
 // (taken from the iteration's cursor with one atomic per range); a lane whose ray is finished
@@ -697,6 +700,7 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
             }
         }
         if (!last) {
+            // (ordering the block's slots by the octant of the new direction was measured: no gain)
             const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (emit) {
                 if (slot < capacity) {
