@@ -169,6 +169,11 @@ int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, i
 int rt_get_stats(rt_context* ctx, rt_stats* out);
 int rt_stats_reset(rt_context* ctx);
 
+/* Measurement aid, no reference counterpart: runs a gather of whole 64-byte records (the BVH node
+ * access pattern) over a table of table_bytes and reports the bytes it loaded, so that rocprofv3's
+ * FETCH_SIZE can be calibrated for this pattern (tools/calib_fetch.py). */
+int rt_debug_gather(rt_context* ctx, uint64_t table_bytes, uint32_t iters, double* bytes_loaded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -573,6 +573,30 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     return 0;
 }
 
+int rt_debug_gather(rt_context* ctx, uint64_t table_bytes, uint32_t iters, double* bytes_loaded) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (table_bytes < 4096 || iters == 0 || !bytes_loaded) return fail(ctx, "invalid argument");
+    DeviceGuard g(ctx->device);
+    const uint64_t n_records = table_bytes / 64;
+    if (n_records > 0xFFFFFFFFull) return fail(ctx, "table too large");
+    float4* table = nullptr;
+    float* sink = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&table, n_records * 64));
+    if (hipMalloc((void**)&sink, 16) != hipSuccess) { (void)hipFree(table); return fail(ctx, "hipMalloc failed"); }
+    int rc = 0;
+    const uint32_t blocks = ctx->cfg.n_cu * 8;
+    if (hipMemsetAsync(table, 0, n_records * 64, ctx->own_stream) != hipSuccess) rc = fail(ctx, "memset failed");
+    if (!rc) {
+        launch_calib_gather(table, (uint32_t)n_records, iters, blocks, sink, ctx->own_stream);
+        hipError_t e = hipStreamSynchronize(ctx->own_stream);
+        if (e != hipSuccess) rc = fail(ctx, "calibration kernel failed: %s", hipGetErrorString(e));
+    }
+    *bytes_loaded = (double)blocks * 256.0 * (double)iters * 64.0;
+    (void)hipFree(table);
+    (void)hipFree(sink);
+    return rc;
+}
+
 int rt_stats_reset(rt_context* ctx) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     DeviceGuard g(ctx->device);

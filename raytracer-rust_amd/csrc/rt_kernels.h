@@ -20,6 +20,7 @@ void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* r
 void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st);
 void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float4* hits, const uint32_t* ctl, uint32_t capacity,
                      int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st);
+void launch_calib_gather(const float4* table, uint32_t n_records, uint32_t iters, uint32_t blocks, float* sink, hipStream_t st);
 void launch_stats(const uint32_t* ctl, unsigned long long* stats, uint32_t capacity, hipStream_t st);
 
 }  // namespace rtamd

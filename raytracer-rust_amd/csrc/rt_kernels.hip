@@ -810,6 +810,22 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     nout[px * 3 + 0] = nrm.x; nout[px * 3 + 1] = nrm.y; nout[px * 3 + 2] = nrm.z;
 }
 
+// Calibration of the rocprofv3 FETCH_SIZE counter for this path's access pattern: every lane reads
+// whole 64-byte records (four 16-byte loads, like a BVH node) at pseudo-random places of a table far
+// larger than the Infinity Cache, so the bytes that must come from HBM are known exactly.
+__global__ __launch_bounds__(256) void k_calib_gather(const float4* __restrict__ table, uint32_t n_records, uint32_t iters,
+                                                      float* __restrict__ sink) {
+    uint32_t h = pcg_hash(blockIdx.x * blockDim.x + threadIdx.x);
+    float acc = 0.f;
+    for (uint32_t k = 0; k < iters; ++k) {
+        h = pcg_hash(h + k);
+        const float4* r = table + 4 * (size_t)(h % n_records);
+        const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+        acc += a.x + b.y + c.z + d.w;
+    }
+    if (acc == 12345.678f) sink[0] = acc;   // keeps the loads alive
+}
+
 // adds the pass's counters into the persistent 64-bit statistics
 __global__ void k_stats(const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ stats, uint32_t capacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -852,6 +868,9 @@ void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_
 void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float4* hits, const uint32_t* ctl, uint32_t capacity,
                      int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st) {
     hipLaunchKernelGGL(k_hit_info, dim3(cdiv(pp.n_paths, 256)), dim3(256), 0, st, sc, pp, q, hits, ctl, capacity, obj, tri, t, nrm);
+}
+void launch_calib_gather(const float4* table, uint32_t n_records, uint32_t iters, uint32_t blocks, float* sink, hipStream_t st) {
+    hipLaunchKernelGGL(k_calib_gather, dim3(blocks), dim3(256), 0, st, table, n_records, iters, sink);
 }
 void launch_stats(const uint32_t* ctl, unsigned long long* stats, uint32_t capacity, hipStream_t st) {
     hipLaunchKernelGGL(k_stats, dim3(cdiv(CTL_MAX_IT + 3, 64)), dim3(64), 0, st, ctl, stats, capacity);
