@@ -46,6 +46,12 @@ int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uin
 int rt_host_read_png(const char* path, uint8_t** rgb8, uint32_t* width, uint32_t* height, char* err, size_t err_len);
 void rt_host_free(void* p);
 
+/* No reference counterpart (the reference has one AABB per mesh, mesh.rs:318-326): builds the BVH
+ * the closest-hit kernel traverses over n boxes (6 floats each: min xyz, max xyz) and verifies it on
+ * the CPU -- every primitive in exactly one leaf, every quantised child box contains its subtree,
+ * the reported traversal-stack bound holds. */
+int rt_host_bvh_validate(uint64_t n, const float* boxes, uint32_t* n_nodes, uint32_t* depth, uint32_t* max_stack, char* err, size_t err_len);
+
 /* raytracer::compute_image (raytrace.rs:108-156) on the GPU `device_id`:
  * load, upload, render all N*N samples at `depth`, resolve, write the PNG. */
 int rt_host_compute_image(const char* ssaa, uint32_t depth, const char* scene_path, const char* output_path, const char* base_dir,

@@ -113,6 +113,34 @@ def test_c4_torus_primary_hits(ctx):
     print("C4 (10k tris) 192x108: %d id mismatches" % bad)
 
 
+def test_c5_combined_primary_hits(ctx):
+    sc = scenegen.scene_c5(width=240, height=135, nu=80, nv=40)     # 485 spheres + 6,400 triangles
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
+    assert (want["triangle_id"] >= 0).sum() > 500 and (want["object_id"] == 0).sum() > 1000    # torus and ground in view
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=6, curved=True)
+    print("C5 (6.4k tris + spheres) 240x135: %d id mismatches" % bad)
+
+
+def test_deep_traversal_stack_spills_correctly(ctx):
+    """4,096 stacked parallel triangles pierced by every ray: all four children of every node are hit,
+    so the per-lane stack outgrows its LDS part (16 entries) and uses the global overflow area."""
+    n = 4096
+    z = -np.arange(n, dtype=np.float64) * 0.01
+    base = np.array([[-3.0, -3.0, 0.0], [3.0, -3.0, 0.0], [0.0, 4.0, 0.0]])
+    verts = (base[None, :, :] + np.stack([np.zeros(n), np.zeros(n), z], axis=1)[:, None, :]).reshape(-1, 3)
+    tris = np.arange(3 * n).reshape(n, 3)
+    order = np.random.default_rng(1).permutation(n)           # file order != depth order
+    objs = [dict(type="Mesh", verts=verts, tris=tris[order], materials=[dict(type="Emissive", color=[1, 1, 1])])]
+    osc = small_scene(ctx, objs, 48, 48)
+    st = ctx.stats()
+    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    assert (want["triangle_id"] >= 0).sum() > 500
+    check_hits(got, want)
+    assert np.all(want["triangle_id"][want["triangle_id"] >= 0] == int(np.nonzero(order == 0)[0][0]))
+
+
 # ------------------------------------------------------------------ images
 def psnr(a, b):
     mse = np.mean((a - b) ** 2)
@@ -149,6 +177,20 @@ def test_c3_image_parity_small(ctx):
     p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
     print("C3 160x90: PSNR %.2f dB at %d spp" % (p, n * n))
     assert p >= 38.0
+
+
+def test_c5_image_parity_small(ctx):
+    """Lambertian mesh + spheres: exercises the triangle self-hit quirk on a curved mesh."""
+    sc = scenegen.scene_c5(width=128, height=72, nu=60, nv=30)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    n = 20
+    acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=5, seed=5))
+    ref = osc.render(mode="jitter", N=n, depth=5, seed=23)
+    p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
+    ref2 = osc.render(mode="jitter", N=n, depth=5, seed=24)
+    print("C5 128x72 (3.6k tris): PSNR %.2f dB at %d spp (oracle seed-to-seed floor %.2f dB)" % (p, n * n, psnr(ref2["color"], ref["color"])))
+    assert p >= 40.0
 
 
 def test_golden_plateaus_of_the_reference_renders(ctx):

@@ -184,3 +184,40 @@ def test_torus_has_one_million_triangles():
     a, b, c = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
     area2 = np.linalg.norm(np.cross(b - a, c - a), axis=1)
     assert area2.min() > 1e-9     # no degenerate triangle (SURVEY A.5 NaN hazard)
+
+
+def _bvh_validate(boxes):
+    L = rt.load_library()
+    b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    nn, dd, ms = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    err = C.create_string_buffer(512)
+    rc = L.rt_host_bvh_validate(len(b), b.ctypes.data, C.byref(nn), C.byref(dd), C.byref(ms), err, 512)
+    assert rc == 0, err.value.decode()
+    return nn.value, dd.value, ms.value
+
+
+def test_bvh_builder_is_conservative_and_complete():
+    rng = np.random.default_rng(3)
+    # edge cases: empty, one primitive, identical boxes, flat boxes, huge dynamic range
+    assert _bvh_validate(np.zeros((0, 6)))[0] == 0
+    assert _bvh_validate([[0, 0, 0, 1, 1, 1]])[0] == 1
+    _bvh_validate(np.tile([[1, 2, 3, 1, 2, 3]], (37, 1)))
+    c = rng.uniform(-1, 1, (500, 3))
+    flat = np.concatenate([c, c + [0.1, 0.0, 0.2]], axis=1)
+    _bvh_validate(flat)
+    far = np.concatenate([c * [1e6, 1e-3, 1.0], c * [1e6, 1e-3, 1.0] + 1e-4], axis=1)
+    _bvh_validate(far)
+    # random clouds, including the parallel build path (>= 65536 primitives)
+    for n in (2, 3, 5, 100, 5000, 70000):
+        c = rng.normal(0, 10, (n, 3))
+        e = rng.uniform(0, 0.5, (n, 3))
+        nodes, depth, stack = _bvh_validate(np.concatenate([c - e, c + e], axis=1))
+        assert nodes >= 1 and depth >= 1 and stack >= 1
+
+
+def test_bvh_of_the_million_triangle_torus():
+    verts, tris = scenegen.torus_mesh()
+    v = verts[tris].astype(np.float32)
+    boxes = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
+    nodes, depth, stack = _bvh_validate(boxes)
+    assert depth <= 16 and stack <= 48 and nodes < 1000000
