@@ -1,0 +1,112 @@
+//! UNTESTED sketch of the patched `compute_image` (src/raytracer/raytrace.rs:108-156) for a maintainer
+//! of bsati/raytracer-rust.  It keeps the reference's loading code (lines 114-125) and replaces the
+//! rayon loop (126-154) by one call into librtamd.so.  It needs three small additions to the
+//! reference: `pub` getters for the four private `Camera` fields (camera.rs:7-12), `pub` access to the
+//! material fields (materials.rs:40-43,68-71,90-94,155-159) and `image::write_rgb8` below.
+//! The flattening mirrors `load_scene()` in raytracer-rust_amd/csrc/rt_host.cpp, which is the tested
+//! statement of the same logic.
+use rtamd_sys::*;
+use std::ptr;
+
+struct Flat {
+    mat_type: Vec<i32>, mat_rgb: Vec<f64>, mat_param: Vec<f64>, mat_texture: Vec<i32>,
+    tex_w: Vec<u32>, tex_h: Vec<u32>, tex_data: Vec<Vec<u8>>,
+    sph_c: Vec<f64>, sph_r: Vec<f64>, sph_m: Vec<i32>, sph_o: Vec<i32>,
+    pl_c: Vec<f64>, pl_n: Vec<f64>, pl_m: Vec<i32>, pl_o: Vec<i32>,
+    tri_v: Vec<f64>, tri_uv: Vec<f64>, tri_has_uv: Vec<u8>, tri_m: Vec<i32>, tri_o: Vec<i32>, tri_i: Vec<i32>,
+    lights: Vec<f64>,
+}
+
+fn push_material(f: &mut Flat, m: &Material) -> i32 {
+    let (t, rgb, p, tex) = match m {
+        Material::Lambertian(l) => (RT_MAT_LAMBERTIAN, l.albedo, 0.0, -1),
+        Material::Metal(x) => (RT_MAT_METAL, x.albedo, x.fuzziness, -1),
+        Material::Dieletrics(d) => (RT_MAT_DIELECTRIC, d.tint, d.refraction_index, -1),
+        Material::Emissive(e) => (RT_MAT_EMISSIVE, e.color, 0.0, -1),
+        Material::Texture(tm) => {
+            // pixel_colors were loaded by Scene::precompute (scene.rs:59-65); bytes = round(c * 255.999)
+            f.tex_w.push(tm.width as u32);
+            f.tex_h.push(tm.height as u32);
+            f.tex_data.push(tm.pixel_colors.iter().flat_map(|c| c.to_output()).collect());
+            (RT_MAT_TEXTURE, Color::new(0.0, 0.0, 0.0), 0.0, f.tex_w.len() as i32 - 1)
+        }
+    };
+    f.mat_type.push(t);
+    f.mat_rgb.extend_from_slice(&[rgb.r, rgb.g, rgb.b]);
+    f.mat_param.push(p);
+    f.mat_texture.push(tex);
+    f.mat_type.len() as i32 - 1
+}
+
+pub fn compute_image(ssaa: SuperSampling, depth: u8, scene_path: &Path, output_path: &Path) {
+    let scene_file = fs::File::open(scene_path).unwrap();
+    let mut scene: scene::Scene = serde_yaml::from_reader(scene_file).unwrap();
+    let camera = camera::Camera::new(scene.camera.eye, scene.camera.look_at, scene.camera.up, scene.camera.fovy, scene.width, scene.height);
+    scene.precompute();
+
+    let mut f = Flat::default();
+    for (oi, o) in scene.objects.iter().enumerate() {
+        match o {
+            Object::Sphere(s) => {
+                f.sph_c.extend_from_slice(&[s.center.x(), s.center.y(), s.center.z()]);
+                f.sph_r.push(s.radius);
+                let m = push_material(&mut f, &s.material);
+                f.sph_m.push(m);
+                f.sph_o.push(oi as i32);
+            }
+            Object::Plane(p) => {
+                f.pl_c.extend_from_slice(&[p.center.x(), p.center.y(), p.center.z()]);
+                f.pl_n.extend_from_slice(&[p.normal.x(), p.normal.y(), p.normal.z()]);
+                let m = push_material(&mut f, &p.material);
+                f.pl_m.push(m);
+                f.pl_o.push(oi as i32);
+            }
+            Object::Mesh(mesh) => {
+                let mats: Vec<i32> = mesh.materials.iter().map(|m| push_material(&mut f, m)).collect();
+                for (ti, t) in mesh.triangles.iter().enumerate() {
+                    for k in 0..3 {
+                        let v = mesh.vertex_positions[t.vertex_idx[k]];
+                        f.tri_v.extend_from_slice(&[v.x(), v.y(), v.z()]);
+                    }
+                    match t.uv_idx {
+                        Some(uv) => { for k in 0..3 { f.tri_uv.extend_from_slice(&[mesh.uvs[uv[k]].0, mesh.uvs[uv[k]].1]); } f.tri_has_uv.push(1); }
+                        None => { f.tri_uv.extend_from_slice(&[0.0; 6]); f.tri_has_uv.push(0); }
+                    }
+                    f.tri_m.push(mats[t.material_idx]);
+                    f.tri_o.push(oi as i32);
+                    f.tri_i.push(ti as i32);
+                }
+            }
+        }
+    }
+    for l in &scene.lights {
+        let p = l.sample_points[0];              // raytrace.rs:81 only ever uses sample_points[0]
+        f.lights.extend_from_slice(&[p.x(), p.y(), p.z()]);
+    }
+    let tex_ptrs: Vec<*const u8> = f.tex_data.iter().map(|t| t.as_ptr()).collect();
+    let v3 = |v: Vector3| [v.x(), v.y(), v.z()];
+    let desc = rt_scene_desc {
+        width: scene.width as u32, height: scene.height as u32,
+        background: [scene.background.r, scene.background.g, scene.background.b],
+        cam_eye: v3(camera.eye()), cam_lower_left: v3(camera.lower_left()), cam_horizontal: v3(camera.horizontal()), cam_vertical: v3(camera.vertical()),
+        n_materials: f.mat_type.len() as u32, mat_type: f.mat_type.as_ptr(), mat_rgb: f.mat_rgb.as_ptr(), mat_param: f.mat_param.as_ptr(), mat_texture: f.mat_texture.as_ptr(),
+        n_textures: f.tex_w.len() as u32, tex_width: f.tex_w.as_ptr(), tex_height: f.tex_h.as_ptr(), tex_rgb8: tex_ptrs.as_ptr(),
+        n_spheres: f.sph_r.len() as u32, sphere_center: f.sph_c.as_ptr(), sphere_radius: f.sph_r.as_ptr(), sphere_material: f.sph_m.as_ptr(), sphere_object: f.sph_o.as_ptr(),
+        n_planes: f.pl_m.len() as u32, plane_center: f.pl_c.as_ptr(), plane_normal: f.pl_n.as_ptr(), plane_material: f.pl_m.as_ptr(), plane_object: f.pl_o.as_ptr(),
+        n_triangles: f.tri_m.len() as u64, tri_vertices: f.tri_v.as_ptr(), tri_uv: f.tri_uv.as_ptr(), tri_has_uv: f.tri_has_uv.as_ptr(),
+        tri_material: f.tri_m.as_ptr(), tri_object: f.tri_o.as_ptr(), tri_index: f.tri_i.as_ptr(),
+        n_lights: (f.lights.len() / 3) as u32, light_point: f.lights.as_ptr(),
+    };
+    let (mode, n) = match ssaa { SuperSampling::Uniform(n) => (RT_SSAA_UNIFORM, n), SuperSampling::Jitter(n) => (RT_SSAA_JITTER, n) };
+    let params = rt_render_params { ssaa_mode: mode, ssaa_n: n as u32, depth: depth as u32, seed: rand::random(), ..Default::default() };
+    let mut rgb8 = vec![0u8; scene.width * scene.height * 3];
+    unsafe {
+        let mut ctx: *mut rt_context = ptr::null_mut();
+        let check = |rc: i32, ctx: *const rt_context| if rc != 0 { panic!("{}", std::ffi::CStr::from_ptr(rt_last_error(ctx)).to_string_lossy()) };
+        check(rt_context_create(0, &mut ctx), ptr::null());
+        check(rt_scene_upload(ctx, &desc), ctx);
+        check(rt_render_image(ctx, &params, ptr::null_mut(), rgb8.as_mut_ptr()), ctx);
+        rt_context_destroy(ctx);
+    }
+    image::write_rgb8(&rgb8, scene.width, scene.height, output_path);   // image.rs:155-162 without to_u8_buf
+}
