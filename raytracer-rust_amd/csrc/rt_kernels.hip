@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
     __shared__ uint32_t lds_stack[4 * LDS_STACK * 64];
     const uint32_t lane = lane_id();
-    uint32_t* const stk = lds_stack + (threadIdx.x >> 6) * (LDS_STACK * 64u) + lane;
+    // address-space-qualified so that stack accesses stay ds_read/ds_write (never flat)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const stk = (lds_u32*)lds_stack + (threadIdx.x >> 6) * (LDS_STACK * 64u) + lane;
     uint32_t* const spill = sc.spill + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * sc.spill_levels) * 64u + lane;
     auto push = [&](uint32_t& sp_, uint32_t v) {
         if (sp_ < LDS_STACK) stk[sp_ * 64u] = v;
@@ -274,7 +276,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     };
     auto pop = [&](uint32_t& sp_) -> int32_t {
         sp_--;
-        return (int32_t)(sp_ < LDS_STACK ? stk[sp_ * 64u] : spill[(size_t)(sp_ - LDS_STACK) * 64u]);
+        // the LDS read is unconditional (clamped index) and the rare deep entry overrides it: a select
+        // between an LDS and a global address would turn into a flat load
+        uint32_t v = stk[min(sp_, LDS_STACK - 1u) * 64u];
+        if (sp_ >= LDS_STACK) v = spill[(size_t)(sp_ - LDS_STACK) * 64u];
+        return (int32_t)v;
     };
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const float4* __restrict__ nodes = sc.nodes;
