@@ -408,9 +408,15 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 // q * (s * idir) are exact and one FMA per plane carries two roundings in all
                 const float sxi = sx * idx, syi = sy * idy, szi = sz * idz;
                 const float bxi = pox * idx, byi = poy * idy, bzi = poz * idz;
-                // bound of the rounding error of those distances
-                const float eps = 0x1p-22f * fmaxf(fmaxf((fabsf(pox) + 256.f * sx) * fabsf(idx), (fabsf(poy) + 256.f * sy) * fabsf(idy)),
-                                                   (fabsf(poz) + 256.f * sz) * fabsf(idz));
+                // Bound of the rounding error of those distances, PER AXIS: 2^-21 (|p-o| + 256 s) |idir|,
+                // moved into the constant term of the near (-) and far (+) planes.  One bound for all three
+                // axes (their maximum) is just as safe but useless: an axis the ray is almost parallel to
+                // has a huge |idir|, and its bound would then loosen the other two slabs so far that such
+                // a ray walks most of the tree (those few rays were the multi-ms tail of a launch).
+                const float wx = fmaf(256.f, sx, fabsf(pox)) * fabsf(idx), wy = fmaf(256.f, sy, fabsf(poy)) * fabsf(idy),
+                            wz = fmaf(256.f, sz, fabsf(poz)) * fabsf(idz);
+                const float bnx = fmaf(wx, -0x1p-21f, bxi), bny = fmaf(wy, -0x1p-21f, byi), bnz = fmaf(wz, -0x1p-21f, bzi);
+                const float bfx = fmaf(wx, 0x1p-21f, bxi), bfy = fmaf(wy, 0x1p-21f, byi), bfz = fmaf(wz, 0x1p-21f, bzi);
                 // entry / exit planes by the sign of the ray direction
                 const uint32_t qlx = __float_as_uint(L2.x), qly = __float_as_uint(L2.y), qlz = __float_as_uint(L2.z);
                 const uint32_t qhx = __float_as_uint(L2.w), qhy = __float_as_uint(L3.x), qhz = __float_as_uint(L3.y);
@@ -422,14 +428,14 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 uint32_t nhit = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float tnx = fmaf((float)((enx >> (8 * c)) & 0xFFu), sxi, bxi);
-                    const float tny = fmaf((float)((eny >> (8 * c)) & 0xFFu), syi, byi);
-                    const float tnz = fmaf((float)((enz >> (8 * c)) & 0xFFu), szi, bzi);
-                    const float tfx = fmaf((float)((exx >> (8 * c)) & 0xFFu), sxi, bxi);
-                    const float tfy = fmaf((float)((exy >> (8 * c)) & 0xFFu), syi, byi);
-                    const float tfz = fmaf((float)((exz >> (8 * c)) & 0xFFu), szi, bzi);
-                    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz) - eps, 0.f);
-                    const float tf = fminf(fminf(fminf(tfx, tfy), tfz) + eps, best.t);
+                    const float tnx = fmaf((float)((enx >> (8 * c)) & 0xFFu), sxi, bnx);
+                    const float tny = fmaf((float)((eny >> (8 * c)) & 0xFFu), syi, bny);
+                    const float tnz = fmaf((float)((enz >> (8 * c)) & 0xFFu), szi, bnz);
+                    const float tfx = fmaf((float)((exx >> (8 * c)) & 0xFFu), sxi, bfx);
+                    const float tfy = fmaf((float)((exy >> (8 * c)) & 0xFFu), syi, bfy);
+                    const float tfz = fmaf((float)((exz >> (8 * c)) & 0xFFu), szi, bfz);
+                    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.f);
+                    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best.t);
                     const bool h = tn <= tf && cc[c] != CHILD_EMPTY_CODE;
                     nhit += h ? 1u : 0u;
                     // sortable key: distance bits (non-negative float == monotonic uint) with the slot in the low bits
