@@ -181,7 +181,8 @@ def main():
                          "traffic": traffic, "kernel": "k_closest_hit", "launches": st["hit_launches"], "ms_per_launch": ms_per_launch,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
                          "prims_per_ray": prims_per_ray, "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
-                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS},
+                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS,
+                         "rays_per_iteration_per_step": [x / args.steps for x in st["rays_per_iteration"][:8]]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)

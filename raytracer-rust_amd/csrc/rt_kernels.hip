@@ -254,8 +254,12 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 // takes the next index of the range, so the 64 lanes stay busy although rays need very different
 // numbers of traversal steps (with one ray per lane per round, 25 % of the VALU lanes were active
 // on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU).
+#ifndef RT_VOTE_WN
+#define RT_VOTE_WN 13   // relative cost of a node step ...
+#define RT_VOTE_WL 9    // ... and of a leaf step (instructions)
+#endif
 #ifndef RT_HIT_MIN_WAVES
-#define RT_HIT_MIN_WAVES 1   // min waves per SIMD the register allocator must allow (tuning)
+#define RT_HIT_MIN_WAVES 6   // min waves per SIMD the register allocator must allow: 80 VGPRs (measured: 5 -> 1.125 ms, 6 -> 1.080, 7 -> 1.138, 8 -> 1.49)
 #endif
 
 template <bool COUNT>
@@ -384,20 +388,22 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         }
 
         // ---------------- traversal steps until enough lanes ran out of work.
-        // Every step is ONE memory round trip for every lane: a lane is either at an inner node
-        // (four 16-byte words) or at one primitive of a leaf (three words); both kinds of loads are
-        // issued together before either result is used.
+        // Every step is ONE memory round trip: a lane is either at an inner node (four 16-byte words)
+        // or at one primitive of a leaf (three words).
         for (;;) {
             const bool leafm = active && pcur < pend;
             const bool nodem = active && !leafm;
-            float4 L0 = make_float4(0.f, 0.f, 0.f, 0.f), L1 = L0, L2 = L0, L3 = L0;
-            if (active) {
-                const float4* __restrict__ base = leafm ? prims + 3 * (size_t)pcur : nodes + 4 * (size_t)node;
-                L0 = base[0]; L1 = base[1]; L2 = base[2];
-                if (nodem) L3 = base[3];
-            }
+            // The wave runs EITHER the node code or the leaf code in a step, whichever has more lanes
+            // waiting (weighted by what the two cost); the lanes of the other kind sit the step out.
+            // Running both in every step costs the sum of the two for the work of one.  (The choice is
+            // wave-uniform, so each side is straight-line code behind a scalar branch; masking the two
+            // sides of a merged step by the same vote measured 12 % slower.)
+            const uint32_t nn = (uint32_t)__popcll(__ballot(nodem)), nl = (uint32_t)__popcll(__ballot(leafm));
+            const bool do_node = nn * RT_VOTE_WL >= nl * RT_VOTE_WN;
             int32_t nxt = STEP_KEEP;
-            if (nodem) {
+            if (do_node && nodem) {
+                const float4* __restrict__ base = nodes + 4 * (size_t)node;
+                const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
                 // 4-wide node, 8-bit child boxes relative to (p, 2^e) -- bvh.h
                 if (COUNT) cnt_nodes++;
                 const uint32_t ex = __float_as_uint(L0.w);
@@ -461,7 +467,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     nxt = cc[0];
                 }
             }
-            if (leafm) {
+            if (!do_node && leafm) {
+                const float4* __restrict__ base = prims + 3 * (size_t)pcur;
+                const float4 L0 = base[0], L1 = base[1], L2 = base[2];
                 if (COUNT) cnt_prims++;
                 const uint32_t pi = pcur;
                 const uint32_t gid = __float_as_uint(L2.y);

@@ -1,0 +1,7 @@
+#!/bin/bash
+# tools/build_variant.sh <name> [extra hipcc flags...]  -> variants/librtamd_<name>.so (for tools/ab.sh)
+set -e
+name=$1; shift
+mkdir -p variants
+cd raytracer-rust_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -Wall -Wno-unused-function -Wno-unused-result "$@" -shared -o ../../variants/librtamd_$name.so rt_kernels.hip rt_api.hip rt_host.cpp bvh.cpp -lz -lpthread
