@@ -245,7 +245,7 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
 constexpr int32_t STEP_KEEP = 0x7FFFFFFE;        // traversal step result: stay in the current leaf
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
 #ifndef RT_REFILL
-#define RT_REFILL 16
+#define RT_REFILL 32
 #endif
 constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this many lanes have no ray
 
