@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
 }
 
 // ---------------------------------------------------------------- closest hit
+typedef float v4f __attribute__((ext_vector_type(4)));
 struct Best {
     float t;
     uint32_t code;   // HIT_MISS, prim index (leaf order) or HIT_PLANE_BIT | plane
@@ -286,6 +287,18 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         if (sp_ >= LDS_STACK) v = spill[(size_t)(sp_ - LDS_STACK) * 64u];
         return (int32_t)v;
     };
+    // planes and big spheres (what every ray tests outside the BVH) staged in LDS
+    constexpr uint32_t FIXED_PLANES = 4, FIXED_SPHERES = 4;
+    __shared__ v4f fixed[2 * FIXED_PLANES + 3 * FIXED_SPHERES];
+    {
+        const uint32_t np = min(sc.n_planes, FIXED_PLANES), ns = min(sc.n_prims - sc.n_leaf_prims, FIXED_SPHERES);
+        if (threadIdx.x < 2u * np) { const float4 v = sc.planes[threadIdx.x]; fixed[threadIdx.x] = v4f{v.x, v.y, v.z, v.w}; }
+        if (threadIdx.x >= 64u && threadIdx.x - 64u < 3u * ns) {
+            const float4 v = sc.prims[3 * (size_t)sc.n_leaf_prims + threadIdx.x - 64u];
+            fixed[2 * FIXED_PLANES + threadIdx.x - 64u] = v4f{v.x, v.y, v.z, v.w};
+        }
+        __syncthreads();
+    }
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ prims = sc.prims;
@@ -326,17 +339,39 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     cur = min(cur + (uint32_t)__popcll(idle), cur_end);
                     if (take) {
                         ray = cand;
-                        const float4 B = q.b[ray];
+                        // A refill is a chain of dependent memory round trips during which the wave's other
+                        // lanes wait, so it is kept to two: (ray words a and b) -> (record of the primitive
+                        // the ray starts on).  Planes and big spheres come from LDS.
+                        const float4 B = q.b[ray], A = q.a[ray];
                         src = __float_as_uint(B.z);
                         if (src == SRC_INVALID) {
                             hits[ray] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);   // padding slot
                         } else {
-                            const float4 A = q.a[ray];
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
                             best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
+                            // a ray that starts on a triangle tests that triangle with the reference's own
+                            // operation sequence (see tri_hit_ref); the traversal below skips it
+                            if (src < sc.n_leaf_prims) {
+                                const float4* __restrict__ sp_ = prims + 3 * (size_t)src;
+                                const float4 s0 = sp_[0], s1 = sp_[1], s2 = sp_[2];
+                                if (__float_as_uint(s2.z) == PRIM_TRIANGLE) {
+                                    float t, a, b;
+                                    if (COUNT) cnt_prims++;
+                                    if (tri_hit_ref(o, d, mk(s0.x, s0.y, s0.z), mk(s0.w, s1.x, s1.y), mk(s1.z, s1.w, s2.x), t, a, b))
+                                        consider(best, t, src, __float_as_uint(s2.y), a, b);
+                                }
+                            }
+                            // (the pointer is laundered so that the reads stay here: hoisted out of the loop
+                            // they would occupy 80 registers for the whole kernel)
+                            typedef __attribute__((address_space(3))) v4f lds_f4;
+                            auto ld = [](lds_f4* q_) { const v4f v = *q_; return make_float4(v.x, v.y, v.z, v.w); };
+                            lds_f4* fx = (lds_f4*)fixed;
+                            asm volatile("" : "+v"(fx));
                             // planes: short linear list (they are unbounded).  intersections.rs:82-104
                             for (uint32_t p = 0; p < sc.n_planes; ++p) {
-                                const float4 P0 = sc.planes[2 * p], P1 = sc.planes[2 * p + 1];
+                                float4 P0, P1;
+                                if (p < FIXED_PLANES) { P0 = ld(fx + 2 * p); P1 = ld(fx + 2 * p + 1); }
+                                else { P0 = sc.planes[2 * p]; P1 = sc.planes[2 * p + 1]; }
                                 const f3 nrm = mk(P1.x, P1.y, P1.z);
                                 const float dn = dot(nrm, d);
                                 if (fabsf(dn) < 1e-6f) continue;
@@ -347,22 +382,13 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             }
                             // big spheres (kept out of the BVH), full f64
                             for (uint32_t pi = sc.n_leaf_prims; pi < sc.n_prims; ++pi) {
-                                const float4 r0 = prims[3 * pi], r1 = prims[3 * pi + 1], r2 = prims[3 * pi + 2];
+                                const uint32_t k = pi - sc.n_leaf_prims;
+                                float4 r0, r1, r2;
+                                if (k < FIXED_SPHERES) { r0 = ld(fx + 2 * FIXED_PLANES + 3 * k); r1 = ld(fx + 2 * FIXED_PLANES + 3 * k + 1); r2 = ld(fx + 2 * FIXED_PLANES + 3 * k + 2); }
+                                else { r0 = prims[3 * pi]; r1 = prims[3 * pi + 1]; r2 = prims[3 * pi + 2]; }
                                 if (COUNT) cnt_prims++;
                                 const float t = sphere_hit64(r0, r1, o, d, src == pi);
                                 if (t > 0.f) consider(best, t, pi, __float_as_uint(r2.y), 0.f, 0.f);
-                            }
-                            // a ray that starts on a triangle tests that triangle with the reference's own
-                            // operation sequence (see tri_hit_ref); the traversal below skips it
-                            if (src < sc.n_leaf_prims) {
-                                const float4 r2 = prims[3 * src + 2];
-                                if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                                    const float4 r0 = prims[3 * src], r1 = prims[3 * src + 1];
-                                    float t, a, b;
-                                    if (COUNT) cnt_prims++;
-                                    if (tri_hit_ref(o, d, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), t, a, b))
-                                        consider(best, t, src, __float_as_uint(r2.y), a, b);
-                                }
                             }
                             if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
