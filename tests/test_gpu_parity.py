@@ -134,11 +134,41 @@ def test_deep_traversal_stack_spills_correctly(ctx):
     order = np.random.default_rng(1).permutation(n)           # file order != depth order
     objs = [dict(type="Mesh", verts=verts, tris=tris[order], materials=[dict(type="Emissive", color=[1, 1, 1])])]
     osc = small_scene(ctx, objs, 48, 48)
-    st = ctx.stats()
     got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
     assert (want["triangle_id"] >= 0).sum() > 500
     check_hits(got, want)
     assert np.all(want["triangle_id"][want["triangle_id"] >= 0] == int(np.nonzero(order == 0)[0][0]))
+
+
+def test_axis_parallel_rays_do_not_walk_the_tree(ctx):
+    """Rays with a zero or tiny direction component (here: the centre column and row of an on-axis
+    camera, d = (0, 0, -1) in the middle) have a huge 1/d on that axis.  The rounding bound of the
+    node test is per axis, so they are culled like any other ray: same hits as the oracle, and the
+    nodes visited per ray stay what a BVH walk costs (one bound shared by the three axes made such
+    rays visit most of the tree)."""
+    n = 96
+    # grid lines off the pixel centres and off the cell diagonals (no rays through shared edges)
+    X, Y = np.meshgrid(np.linspace(-2.013, 1.987, n + 1), np.linspace(-2.0071, 1.9929, n + 1), indexing="ij")
+    Z = 0.05 * np.sin(3.0 * X) * np.cos(2.0 * Y)
+    verts = np.stack([X, Y, Z], axis=-1).reshape(-1, 3)
+    idx = lambda i, j: i * (n + 1) + j
+    tris = np.array([[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)] for i in range(n) for j in range(n)] +
+                    [[idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)] for i in range(n) for j in range(n)])
+    objs = [dict(type="Mesh", verts=verts, tris=tris, materials=[dict(type="Emissive", color=[1, 1, 1])])]
+    osc = small_scene(ctx, objs, 65, 65)
+    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    assert want["triangle_id"][32, 32] >= 0
+    check_hits(got, want, allow_id_mismatch=2)    # rays through shared edges / vertices of the grid
+    # a one-pixel-wide image: EVERY ray has d.x == 0 (measured with the shared bound: 98 nodes and
+    # 189 triangles per ray; per axis: 9 and 2)
+    for (w, h) in ((1, 65), (65, 1)):
+        small_scene(ctx, objs, w, h)
+        ctx.stats_reset()
+        ctx.render_image(rt.RenderParams("grid:1", depth=1, counters=True, sample_offset=(0.5, 0.5)))
+        st = ctx.stats()
+        assert st["rays_total"] == 65
+        assert st["nodes_visited"] / st["rays_total"] < 20.0 and st["prims_tested"] / st["rays_total"] < 6.0, \
+            (st["nodes_visited"] / st["rays_total"], st["prims_tested"] / st["rays_total"])
 
 
 # ------------------------------------------------------------------ images
