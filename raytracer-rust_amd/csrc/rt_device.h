@@ -19,8 +19,13 @@ constexpr uint32_t HIT_BLOCKS_PER_CU = 8;     // persistent closest-hit blocks (
 // control block (uint32 words, zeroed at the start of every pass)
 constexpr int CTL_MAX_IT = 320;               // == RT_MAX_ITERATIONS
 constexpr int CTL_QCOUNT = 0;                 // [it]   rays in the queue consumed by iteration `it`
-constexpr int CTL_FETCH = CTL_MAX_IT + 8;     // [it]   dynamic-fetch cursor of the closest-hit kernel
-constexpr int CTL_OVERFLOW = 2 * (CTL_MAX_IT + 8);
+constexpr int CTL_FETCH = CTL_MAX_IT + 8;     // [segment][it] dynamic-fetch cursors of the closest-hit kernel: the queue is cut
+#ifndef RT_FETCH_SEGS
+#define RT_FETCH_SEGS 8
+#endif
+constexpr int CTL_FETCH_SEGS = RT_FETCH_SEGS;             //   into 8 segments with one cursor each (a single address sustains ~90 atomics/us)
+constexpr int CTL_FETCH_STRIDE = CTL_MAX_IT + 8;   // words between the cursors of two segments: different cache lines
+constexpr int CTL_OVERFLOW = CTL_FETCH + CTL_FETCH_SEGS * CTL_FETCH_STRIDE;
 constexpr int CTL_NODES_LO = CTL_OVERFLOW + 2;   // 64-bit counters: even word index = 8-byte aligned
 constexpr int CTL_PRIMS_LO = CTL_OVERFLOW + 4;
 constexpr int CTL_WORDS = CTL_OVERFLOW + 8;

@@ -255,6 +255,9 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 // takes the next index of the range, so the 64 lanes stay busy although rays need very different
 // numbers of traversal steps (with one ray per lane per round, 25 % of the VALU lanes were active
 // on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU).
+#ifndef RT_CHUNK_DIV
+#define RT_CHUNK_DIV 8u
+#endif
 #ifndef RT_VOTE_WN
 #define RT_VOTE_WN 13   // relative cost of a node step ...
 #define RT_VOTE_WL 9    // ... and of a leaf step (instructions)
@@ -303,10 +306,15 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ prims = sc.prims;
     uint32_t cnt_nodes = 0, cnt_prims = 0;
-    // rays per range: large enough that the cursor sees few atomics, small enough to balance the grid
+    // The queue is cut into CTL_FETCH_SEGS segments, each with its own cursor.  A wave starts in the
+    // segment of its block (consecutive blocks go to different XCDs) and moves on to the next one
+    // when a segment is used up, so the cursors see an eighth of the atomics each and the ranges can
+    // be small: with one cursor and ranges of 256 the waves finished up to a range apart (4.4 of 6
+    // waves per SIMD resident on average over a launch).
     const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t chunk = min(2048u, max(64u, (n / (total_waves * 4u)) & ~63u));
-
+    const uint32_t chunk = min(2048u, max(64u, (n / (total_waves * RT_CHUNK_DIV)) & ~63u));
+    const uint32_t seg_len = ((n + CTL_FETCH_SEGS - 1) / CTL_FETCH_SEGS + 63u) & ~63u;
+    uint32_t seg = blockIdx.x % CTL_FETCH_SEGS, segs_left = CTL_FETCH_SEGS;
     // wave-uniform range state
     uint32_t cur = 0, cur_end = 0;
     bool exhausted = false;
@@ -325,12 +333,16 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         {
             const uint64_t idle = __ballot(!active);
             if (idle != 0ull) {
-                if (cur >= cur_end && !exhausted) {
+                while (cur >= cur_end && !exhausted) {
+                    const uint32_t seg_begin = seg * seg_len, seg_end = min(seg_begin + seg_len, n);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + it], chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n) exhausted = true;
-                    else { cur = base; cur_end = min(base + chunk, n); }
+                    if (lane == 0) base = atomicAdd(&ctl[CTL_FETCH + seg * CTL_FETCH_STRIDE + it], chunk);
+                    base = seg_begin + __builtin_amdgcn_readfirstlane(base);
+                    if (base < seg_end) { cur = base; cur_end = min(base + chunk, seg_end); }
+                    else {
+                        seg = (seg + 1u) % CTL_FETCH_SEGS;
+                        if (--segs_left == 0u) exhausted = true;
+                    }
                 }
                 if (cur < cur_end) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
