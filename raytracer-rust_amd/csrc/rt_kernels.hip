@@ -243,7 +243,6 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
     return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
 
-constexpr int32_t STEP_KEEP = 0x7FFFFFFE;        // traversal step result: stay in the current leaf
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
 #ifndef RT_REFILL
 #define RT_REFILL 32
@@ -259,8 +258,8 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 #define RT_CHUNK_DIV 8u
 #endif
 #ifndef RT_VOTE_WN
-#define RT_VOTE_WN 13   // relative cost of a node step ...
-#define RT_VOTE_WL 9    // ... and of a leaf step (instructions)
+#define RT_VOTE_WN 2    // a node step is chosen when (lanes with a node) * WL >= (lanes with a parked leaf) * WN
+#define RT_VOTE_WL 1    // (13:9, 1:1, 2:1, 3:1, 9:13 measured)
 #endif
 #ifndef RT_HIT_MIN_WAVES
 #define RT_HIT_MIN_WAVES 6   // min waves per SIMD the register allocator must allow: 80 VGPRs (measured: 5 -> 1.125 ms, 6 -> 1.080, 7 -> 1.138, 8 -> 1.49)
@@ -429,17 +428,23 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         // Every step is ONE memory round trip: a lane is either at an inner node (four 16-byte words)
         // or at one primitive of a leaf (three words).
         for (;;) {
+            // A lane holds up to two pieces of work: an inner node to test (node) and a leaf whose
+            // primitives are pending (pcur < pend).  A ray that reaches a leaf parks it and goes on with
+            // the next node from its stack, so it takes part in node steps AND in leaf steps; the order
+            // in which a ray's nodes and leaves are done does not change the closest hit.
+            //   node: inner node index | STACK_SENTINEL (stack used up) | < 0: a second leaf, waiting
+            //         for the parked one to be finished (the lane then sits node steps out)
             const bool leafm = active && pcur < pend;
-            const bool nodem = active && !leafm;
+            const bool nodem = active && (uint32_t)node < (uint32_t)STACK_SENTINEL;
             // The wave runs EITHER the node code or the leaf code in a step, whichever has more lanes
-            // waiting (weighted by what the two cost); the lanes of the other kind sit the step out.
-            // Running both in every step costs the sum of the two for the work of one.  (The choice is
-            // wave-uniform, so each side is straight-line code behind a scalar branch; masking the two
-            // sides of a merged step by the same vote measured 12 % slower.)
+            // waiting (weighted by what the two cost).  Running both in every step costs the sum of the
+            // two for the work of one.  (The choice is wave-uniform, so each side is straight-line code
+            // behind a scalar branch; masking the two sides of a merged step by the same vote measured
+            // 12 % slower.)
             const uint32_t nn = (uint32_t)__popcll(__ballot(nodem)), nl = (uint32_t)__popcll(__ballot(leafm));
             const bool do_node = nn * RT_VOTE_WL >= nl * RT_VOTE_WN;
-            int32_t nxt = STEP_KEEP;
             if (do_node && nodem) {
+                int32_t nxt;
                 const float4* __restrict__ base = nodes + 4 * (size_t)node;
                 const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
                 // 4-wide node, 8-bit child boxes relative to (p, 2^e) -- bvh.h
@@ -504,6 +509,14 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     if (nhit > 1u) push(sp, (uint32_t)cc[1]);
                     nxt = cc[0];
                 }
+                if (nxt < 0 && !leafm) {
+                    // a leaf (~nxt = (first << 3) | (count - 1)) and nothing parked: park it, go on with the stack
+                    const uint32_t code = (uint32_t)~nxt;
+                    pcur = code >> 3;
+                    pend = pcur + (code & 7u) + 1u;
+                    nxt = pop(sp);
+                }
+                node = nxt;
             }
             if (!do_node && leafm) {
                 const float4* __restrict__ base = prims + 3 * (size_t)pcur;
@@ -534,20 +547,17 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
                 }
                 pcur++;
-                if (pcur == pend) nxt = pop(sp);
-            }
-            if (nxt != STEP_KEEP) {
-                if (nxt == STACK_SENTINEL) {
-                    hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
-                    active = false;
-                } else if (nxt >= 0) {
-                    node = nxt;
-                } else {
-                    // leaf: ~nxt = (first << 3) | (count - 1)
-                    const uint32_t code = (uint32_t)~nxt;
+                if (pcur == pend && node < 0) {
+                    // the leaf that was waiting moves in, the stack gives the next piece of work
+                    const uint32_t code = (uint32_t)~node;
                     pcur = code >> 3;
                     pend = pcur + (code & 7u) + 1u;
+                    node = pop(sp);
                 }
+            }
+            if (active && node == STACK_SENTINEL && pcur >= pend) {
+                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+                active = false;
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             if (n_active == 0u) break;
