@@ -182,7 +182,11 @@ def main():
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
                          "prims_per_ray": prims_per_ray, "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
                          "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS,
-                         "rays_per_iteration_per_step": [x / args.steps for x in st["rays_per_iteration"][:8]]},
+                         "rays_per_iteration_per_step": [x / args.steps for x in st["rays_per_iteration"][:8]],
+                         "note": "achieved = algorithmic bytes (DESIGN.md section 4) / launch time; the 83 MB scene is served by L1/L2/"
+                                 "Infinity Cache (traffic = HBM-side bytes per launch from the PMC passes is ~15% of the algorithmic "
+                                 "bytes), so frac near or above 1 means HBM is not the limiter: the kernel is VALU-issue bound "
+                                 "(85% busy, profiles/r01_pmc_summary_c5_1080p.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)
