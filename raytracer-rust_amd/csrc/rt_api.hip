@@ -286,6 +286,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
     // ---- records: BVH primitives in leaf order, then the big spheres
     std::vector<float4> prims((size_t)n_prims * 3);
     std::vector<int4> meta(n_prims);
+    std::vector<float4> smeta(n_prims);
     std::vector<float> uvs;
     for (uint32_t k = 0; k < n_prims; ++k) {
         uint32_t src = k < n_leaf_prims ? bvh_src[bvh.order[k]] : big_src[k - n_leaf_prims];
@@ -296,6 +297,9 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
             uint32_t w[4] = {0u, gid_sphere[src], PRIM_SPHERE, 0u};
             std::memcpy(&r[2], w, 16);
             meta[k] = make_int4(d->sphere_object[src], -1, d->sphere_material[src], -1);
+            uint32_t mw = (uint32_t)d->sphere_material[src];
+            float mf; std::memcpy(&mf, &mw, 4);
+            smeta[k] = make_float4(0.f, 0.f, 0.f, mf);
         } else {
             uint64_t t = src - d->n_spheres;
             const float* v = &tri_f32[9 * t];
@@ -314,6 +318,15 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
                 for (int q = 0; q < 6; ++q) uvs.push_back((float)d->tri_uv[6 * t + q]);
             }
             meta[k] = make_int4(d->tri_object[t], d->tri_index[t], d->tri_material[t], uv_off);
+            // unit normal in f64 from the f64 vertices (intersections.rs:153-154,169), rounded once
+            const double* V = &d->tri_vertices[9 * t];
+            const double ab[3] = {V[3] - V[0], V[4] - V[1], V[5] - V[2]}, ac[3] = {V[6] - V[0], V[7] - V[1], V[8] - V[2]};
+            double nn[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+            const double nl = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            if (nl > 0.0) { nn[0] /= nl; nn[1] /= nl; nn[2] /= nl; }
+            uint32_t mw = (uint32_t)d->tri_material[t] | (has_uv ? SMETA_HAS_UV : 0u);
+            float mf; std::memcpy(&mf, &mw, 4);
+            smeta[k] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], mf);
         }
     }
     std::vector<float4> nodes(bvh.nodes.size() * 4);
@@ -350,7 +363,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         lights[i] = make_float4((float)d->light_point[3 * i], (float)d->light_point[3 * i + 1], (float)d->light_point[3 * i + 2], 0.f);
 
     DevScene sc{};
-    if (upload(ctx, nodes, &sc.nodes) || upload(ctx, prims, &sc.prims) || upload(ctx, meta, &sc.meta) || upload(ctx, uvs, &sc.uvs) ||
+    if (upload(ctx, nodes, &sc.nodes) || upload(ctx, prims, &sc.prims) || upload(ctx, meta, &sc.meta) || upload(ctx, smeta, &sc.smeta) || upload(ctx, uvs, &sc.uvs) ||
         upload(ctx, planes, &sc.planes) || upload(ctx, plane_obj, &sc.plane_object) || upload(ctx, mats, &sc.materials) ||
         upload(ctx, textures, &sc.textures) || upload(ctx, texels, &sc.texels) || upload(ctx, lights, &sc.lights)) {
         free_scene(ctx);

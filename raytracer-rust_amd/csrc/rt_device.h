@@ -12,6 +12,7 @@ constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primiti
 constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: not a ray
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
+constexpr uint32_t SMETA_HAS_UV = 0x80000000u;
 constexpr int32_t CHILD_EMPTY_CODE = (int32_t)0x80000000;   // == bvh.h CHILD_EMPTY
 constexpr uint32_t LDS_STACK = 16;            // traversal-stack entries per lane kept in LDS (4 KB per wave)
 constexpr uint32_t HIT_BLOCKS_PER_CU = 8;     // persistent closest-hit blocks (256 threads) per CU
@@ -50,10 +51,15 @@ struct RayQueue {
 // index): the tie-break key of scene.rs:43 / intersections.rs:170.
 //
 // meta (int4 per primitive, leaf order): (object index, triangle index or -1, material, uv offset or -1)
+// smeta (float4 per primitive, leaf order), what shading needs: (n.x, n.y, n.z, bits(material | SMETA_HAS_UV)).
+//   n = the triangle's unit normal, normalized((B-A) x (C-A)) (intersections.rs:169) evaluated in f64 on
+//   the host and rounded once.  The device's edges come from f32 vertices: on a 1M-triangle mesh (edges of
+//   0.01 at coordinates of 6) their cross product is off by 1.5e-5, above the 1e-5 bar.  Spheres: n unused.
 struct DevScene {
     const float4* nodes;      // 4 x 16 bytes per 4-wide quantised node (bvh.h)
     const float4* prims;      // 3 x float4 per primitive
     const int4* meta;
+    const float4* smeta;
     const float* uvs;         // 6 floats per primitive that has uv: (u0,v0,u1,v1,u2,v2)
     uint32_t n_prims;         // all primitive records
     uint32_t n_leaf_prims;    // records [0, n_leaf_prims) are referenced by BVH leaves; the rest are big spheres

@@ -689,16 +689,16 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
                     p = at_ref(o, d, t);                                                   // raytrace.rs:40-42
                 } else {
                     const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
-                    const int4 M = sc.meta[code];
-                    mat = M.z;
+                    const float4 S = sc.smeta[code];
+                    mat = (int)(__float_as_uint(S.w) & ~SMETA_HAS_UV);
                     if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
                         const f3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-                        nrm = normalized(cross(e1, e2));                                   // intersections.rs:169
+                        nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
                         // hit point from the reference's own t sequence (see tri_hit_ref)
                         t = tri_t_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2);
                         p = at_ref(o, d, t);                                               // intersections.rs:172
-                        if (M.w >= 0) {                                                    // intersections.rs:177-183
-                            const float* uv = sc.uvs + 6 * (size_t)M.w;
+                        if (__float_as_uint(S.w) & SMETA_HAS_UV) {                         // intersections.rs:177-183
+                            const float* uv = sc.uvs + 6 * (size_t)sc.meta[code].w;
                             const float a = H.z, b = H.w, c = 1.f - a - b;
                             u = a * uv[2] + b * uv[4] + c * uv[0];
                             v = a * uv[3] + b * uv[5] + c * uv[1];
@@ -861,7 +861,8 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
             const int4 M = sc.meta[code];
             o = M.x; t = M.y;
             if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                nrm = normalized(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));
+                const float4 S = sc.smeta[code];
+                nrm = mk(S.x, S.y, S.z);
             } else {
                 const f3 org = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
                 const f3 p = org + d * tt;

@@ -289,6 +289,43 @@ def test_ray_accounting_and_determinism(ctx):
     assert not np.array_equal(a, c)
 
 
+def test_full_size_c5_hits_and_properties(ctx):
+    """BASELINE.json's metric configuration at its full size: 485 spheres + 1,000,000 triangles at
+    1920x1080.  The brute-force oracle checks a 24x12-pixel window on the torus (288 rays x 1M
+    triangles); the whole frame is covered by size-independent properties: ray accounting, no queue
+    overflow, bit-identical repeat, tile-split union == full frame, sample-split linearity."""
+    sc = scenegen.scene_c5()
+    assert sc["width"] == 1920 and sc["height"] == 1080
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    got = ctx.primary_hits(0.0, 0.0)
+    on_mesh = got["triangle_id"] >= 0
+    assert on_mesh.sum() > 20000 and (got["object_id"] >= 0).mean() > 0.5
+    rows, cols = np.nonzero(on_mesh)
+    r0, c0 = int(np.median(rows)), int(np.median(cols))
+    crop = (c0 - 12, c0 + 12, r0 - 6, r0 + 6)                       # x0, x1, row0, row1
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    want = osc.primary_hits(0.0, 0.0, crop=crop)
+    sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
+    assert (want["triangle_id"] >= 0).sum() > 100
+    check_hits(sub_, want, allow_id_mismatch=2, curved=True)
+    one = dict(depth=5, seed=3, sample_begin=0, sample_end=1)          # 1 spp of a jitter:2 grid
+    ctx.stats_reset()
+    full, _ = ctx.render_image(rt.RenderParams("jitter:2", **one))
+    st = ctx.stats()
+    assert st["paths"] == 1920 * 1080 == st["rays_per_iteration"][0] and st["queue_overflow"] == 0
+    assert 2.0 < st["rays_total"] / st["paths"] < 4.0
+    again, _ = ctx.render_image(rt.RenderParams("jitter:2", **one))
+    assert np.array_equal(full, again)                                 # no lights in C5: no float atomics
+    parts = np.zeros_like(full)
+    for k in range(2):
+        a, _ = ctx.render_image(rt.RenderParams("jitter:2", tile_index=k, tile_count=2, **one))
+        parts += a
+    assert np.array_equal(parts, full)
+    two, _ = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=3, sample_begin=0, sample_end=2))
+    b, _ = ctx.render_image(rt.RenderParams("jitter:2", depth=5, seed=3, sample_begin=1, sample_end=2))
+    assert np.allclose(full + b, two, rtol=1e-5, atol=1e-6)
+
+
 def test_device_pointer_api_matches_host_api(ctx):
     import torch
     load_pair("spheres", ctx)
