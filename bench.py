@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--split", default=None, choices=["spp", "tiles"])
+    ap.add_argument("--paths-per-pass", type=int, default=0, help="rt_render_params.max_paths_per_pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-step", type=int, default=6, help="cpu_baseline traces every n-th pixel and row")
     ap.add_argument("--small", action="store_true", help="tiny configuration for plumbing checks (not a valid measurement)")
@@ -91,11 +92,12 @@ def main():
         if split == "spp":
             cell0 = ((k * world + rank) * spp) % (grid_n * grid_n)      # disjoint cell ranges per rank and step
             p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
-                                sample_end=cell0 + spp, timing=timing, counters=counters)
+                                sample_end=cell0 + spp, timing=timing, counters=counters, max_paths_per_pass=args.paths_per_pass)
         else:
             cell0 = (k * spp) % (grid_n * grid_n)
             p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
-                                sample_end=cell0 + spp, tile_index=rank, tile_count=world, timing=timing, counters=counters)
+                                sample_end=cell0 + spp, tile_index=rank, tile_count=world, timing=timing, counters=counters,
+                                max_paths_per_pass=args.paths_per_pass)
         accum.zero_()
         ctx.render_accumulate(p, accum, stream.cuda_stream)
         if world > 1:

@@ -113,7 +113,7 @@ typedef struct rt_render_params {
     uint32_t sample_end;     /* (anti_aliasing.rs:96-100); end = 0 means N*N             */
     uint32_t tile_index;     /* 8x8-pixel tiles are dealt round-robin: this call renders */
     uint32_t tile_count;     /* tiles t with t % tile_count == tile_index; 0 means 1     */
-    uint32_t max_paths_per_pass;     /* 0 = default (16 Mi paths)                        */
+    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths = 17 GB of queues)     */
     uint32_t max_shadow_generations; /* cap of the shadow-ray branching process          */
                                      /* (raytrace.rs:78-85 recursion); 0 = default 16    */
     uint32_t flags;          /* rt_render_flags                                          */
