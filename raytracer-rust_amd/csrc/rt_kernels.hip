@@ -254,6 +254,9 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 // takes the next index of the range, so the 64 lanes stay busy although rays need very different
 // numbers of traversal steps (with one ray per lane per round, 25 % of the VALU lanes were active
 // on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU).
+#ifndef RT_CHUNK_MAX
+#define RT_CHUNK_MAX 256u
+#endif
 #ifndef RT_CHUNK_DIV
 #define RT_CHUNK_DIV 8u
 #endif
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     // be small: with one cursor and ranges of 256 the waves finished up to a range apart (4.4 of 6
     // waves per SIMD resident on average over a launch).
     const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t chunk = min(2048u, max(64u, (n / (total_waves * RT_CHUNK_DIV)) & ~63u));
+    const uint32_t chunk = min(RT_CHUNK_MAX, max(64u, (n / (total_waves * RT_CHUNK_DIV)) & ~63u));   // 128 at 9 M rays, 256 from 17 M on (64..1088 measured)
     const uint32_t seg_len = ((n + CTL_FETCH_SEGS - 1) / CTL_FETCH_SEGS + 63u) & ~63u;
     uint32_t seg = blockIdx.x % CTL_FETCH_SEGS, segs_left = CTL_FETCH_SEGS;
     // wave-uniform range state
