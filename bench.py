@@ -188,7 +188,7 @@ def main():
                          "note": "achieved = algorithmic bytes (DESIGN.md section 4) / launch time; the 83 MB scene is served by L1/L2/"
                                  "Infinity Cache (traffic = HBM-side bytes per launch from the PMC passes is ~15% of the algorithmic "
                                  "bytes), so frac near or above 1 means HBM is not the limiter: the kernel is VALU-issue bound "
-                                 "(85% busy, profiles/r01_pmc_summary_c5_1080p.json)"},
+                                 "(VALU issue saturated, profiles/r01_pmc_summary_c5_1080p.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)
