@@ -414,14 +414,25 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
     const uint32_t gens = sc.n_lights ? (p->max_shadow_generations ? p->max_shadow_generations : 16u) : 0u;
     if (p->depth + gens + 1 > (uint32_t)CTL_MAX_IT) return fail(ctx, "depth + shadow generations exceeds %d", CTL_MAX_IT - 1);
 
-    // tiles per pass / samples per pass
-    const uint32_t tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
-    const uint32_t samples_pass = std::max<uint32_t>(1, std::min<uint32_t>(se - sb, max_paths / (tiles_pass * 64)));
-    const uint32_t pass_paths = tiles_pass * 64 * samples_pass;
-    // a firing path spawns one shadow ray per light (raytrace.rs:78-85)
-    const uint64_t cap64 = (uint64_t)pass_paths * std::max<uint32_t>(1, std::min<uint32_t>(sc.n_lights, 4));
-    if (cap64 > 0xFFFFFF00ull) return fail(ctx, "pass too large");
-    if (ensure_state(ctx, pass_paths, (uint32_t)cap64)) return 1;
+    // tiles per pass / samples per pass.  With the default pass size a device that cannot hold the
+    // queues (128 B per path) gets smaller passes instead of an error.
+    uint32_t tiles_pass, samples_pass;
+    for (;;) {
+        tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
+        samples_pass = std::max<uint32_t>(1, std::min<uint32_t>(se - sb, max_paths / (tiles_pass * 64)));
+        const uint32_t pass_paths = tiles_pass * 64 * samples_pass;
+        // a firing path spawns one shadow ray per light (raytrace.rs:78-85)
+        const uint64_t cap64 = (uint64_t)pass_paths * std::max<uint32_t>(1, std::min<uint32_t>(sc.n_lights, 4));
+        if (cap64 > 0xFFFFFF00ull) {
+            if (!p->max_paths_per_pass && max_paths > (1u << 20)) { max_paths >>= 1; continue; }
+            return fail(ctx, "pass too large");
+        }
+        if (ensure_state(ctx, pass_paths, (uint32_t)cap64) == 0) break;
+        free_state(ctx);
+        (void)hipGetLastError();
+        if (p->max_paths_per_pass || max_paths <= (1u << 20)) return 1;
+        max_paths >>= 1;
+    }
     const uint32_t capacity = ctx->capacity;
     const bool counters = (p->flags & RT_FLAG_COUNTERS) != 0, timing = (p->flags & RT_FLAG_TIMING) != 0;
 
