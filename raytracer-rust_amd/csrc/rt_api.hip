@@ -522,6 +522,14 @@ int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accu
     HIP_TRY(ctx, hipMalloc((void**)&accum, n * sizeof(float)));
     int rc = 0;
     hipStream_t st = ctx->own_stream;
+    // rays dropped because a queue was full (only the branching shadow-ray process of scenes with
+    // several lights can do that, raytrace.rs:78-85) make the image wrong: this call reports them
+    auto dropped = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (ctx->stats_dev) (void)hipMemcpy(&v, ctx->stats_dev + CTL_MAX_IT, sizeof(v), hipMemcpyDeviceToHost);
+        return v;
+    };
+    const unsigned long long dropped_before = dropped();
     do {
         if (hipMemsetAsync(accum, 0, n * sizeof(float), st) != hipSuccess) { rc = fail(ctx, "hipMemsetAsync failed"); break; }
         if ((rc = render_accumulate_impl(ctx, params, accum, st, false, nullptr))) break;
@@ -534,6 +542,9 @@ int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accu
         if (e != hipSuccess) { rc = fail(ctx, "render failed: %s", hipGetErrorString(e)); break; }
         if (accum_host && hipMemcpy(accum_host, accum, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
         if (rgb8_host && hipMemcpy(rgb8_host, rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
+        const unsigned long long lost = dropped() - dropped_before;
+        if (lost) rc = fail(ctx, "%llu rays were dropped: the shadow-ray queue overflowed (%u lights; lower max_shadow_generations or max_paths_per_pass)",
+                            lost, ctx->sc.n_lights);
     } while (0);
     (void)hipFree(accum);
     (void)hipFree(rgb8);

@@ -394,6 +394,32 @@ def test_tie_break_prefers_lower_object_index(ctx):
     assert set(np.unique(got["object_id"])) <= {-1, 0, 2}
 
 
+def test_dropped_shadow_rays_are_an_error(ctx):
+    """raytrace.rs:64-87: on the last bounce a path fires with probability 0.1 * L and then spawns L
+    shadow rays, each of which can fire again.  With 8 lights that is 6.4 rays per path and
+    generation, more than the queues hold (4 per path): the render must say so, not return a
+    darker image."""
+    grey = dict(type="Lambertian", albedo=[0.5, 0.5, 0.5])
+    # a closed room of six planes around the camera: every primary ray scatters
+    objs = [dict(type="Plane", center=c, normal=n, material=grey) for c, n in
+            (([0, -1, 0], [0, 1, 0]), ([0, 3, 0], [0, -1, 0]), ([-5, 0, 0], [1, 0, 0]), ([5, 0, 0], [-1, 0, 0]),
+             ([0, 0, -4], [0, 0, 1]), ([0, 0, 6], [0, 0, -1]))]
+    for k in range(8):
+        objs.append(dict(type="Sphere", center=[-3.5 + k, 2.0, -1.0], radius=0.3, material=dict(type="Emissive", color=[1, 1, 1])))
+    fresh = rt.Context(0)        # queues sized by this render only (a context keeps its largest queues)
+    try:
+        small_scene(fresh, objs, 64, 64)
+        with pytest.raises(Exception, match="dropped"):
+            fresh.render_image(rt.RenderParams("jitter:4", depth=1, seed=1))
+        # two lights (the reference's scenes): fine
+        small_scene(fresh, objs[:8], 64, 64)
+        fresh.stats_reset()
+        fresh.render_image(rt.RenderParams("jitter:4", depth=1, seed=1))
+        assert fresh.stats()["queue_overflow"] == 0
+    finally:
+        fresh.close()
+
+
 def test_invalid_arguments_are_errors(ctx):
     load_pair("cube", ctx)
     with pytest.raises(rt.RtError):
