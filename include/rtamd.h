@@ -156,7 +156,12 @@ int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t spp_total, uint
 
 /* Whole pixel loop of compute_image (raytrace.rs:126-154) with host outputs
  * (either may be NULL): accum_host = per-pixel sum of sample colours (float),
- * rgb8_host = the bytes write_image would store (image.rs:128-135). Synchronous. */
+ * rgb8_host = the bytes write_image would store (image.rs:128-135). Synchronous.
+ * Fails (after filling the outputs) if rays were dropped because a queue was full: only the
+ * branching shadow-ray process of scenes with more than ~4 lights can do that
+ * (raytrace.rs:78-85 spawns L rays per firing path and each can fire again; the reference
+ * itself recurses without bound there).  rt_render_accumulate is asynchronous and reports the
+ * same count through rt_get_stats().queue_overflow. */
 int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accum_host, uint8_t* rgb8_host);
 
 /* Closest hit of ONE primary ray per pixel at sub-pixel offset (dx,dy)
