@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--split", default=None, choices=["spp", "tiles"])
     ap.add_argument("--paths-per-pass", type=int, default=0, help="rt_render_params.max_paths_per_pass (0 = library default)")
+    ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="BVH builder: host binned SAH (default) or GPU linear BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-step", type=int, default=6, help="cpu_baseline traces every n-th pixel and row")
     ap.add_argument("--small", action="store_true", help="tiny configuration for plumbing checks (not a valid measurement)")
@@ -80,6 +81,7 @@ def main():
     t0 = time.time()
     scene = rt.Scene.from_objects(W, H, sc["background"], sc["camera"], sc["objects"])
     ctx = rt.Context(local_rank)
+    ctx.set_bvh_builder(args.bvh)
     ctx.upload(scene)
     upload_s = time.time() - t0
 
@@ -180,7 +182,7 @@ def main():
                                    (name, W, H, args.depth, spp, grid_n, split, " [SMALL: not a measurement]" if args.small else ""),
                        "paths_per_step": total_paths / args.steps, "rays_per_path": total_rays / max(1.0, total_paths),
                        "samples_per_s": total_paths / elapsed, "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"],
-                       "bvh_build_ms": st["bvh_build_ms"], "scene_upload_s": upload_s},
+                       "bvh_build_ms": st["bvh_build_ms"], "bvh_builder": args.bvh, "scene_upload_s": upload_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_closest_hit", "launches": st["hit_launches"], "ms_per_launch": ms_per_launch,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,

@@ -174,6 +174,18 @@ int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, i
 int rt_get_stats(rt_context* ctx, rt_stats* out);
 int rt_stats_reset(rt_context* ctx);
 
+/* No reference counterpart (the reference has one AABB per mesh, mesh.rs:318-326).
+ * Chooses the builder of the BVH that rt_scene_upload makes: 0 = host, binned SAH, threaded (default;
+ * best trees: 0.16 s for 1M triangles), 1 = GPU linear BVH (Morton codes, radix sort, Karras tree,
+ * collapse to the same 4-wide quantised nodes; milliseconds, more nodes per ray). */
+int rt_context_set_bvh_builder(rt_context* ctx, int builder);
+
+/* Builds a BVH over n boxes (6 floats each: min xyz, max xyz) with the context's builder on its
+ * device and verifies it on the CPU like rt_host_bvh_validate: every primitive in exactly one leaf,
+ * every quantised child box contains its subtree, the reported traversal-stack bound holds. */
+int rt_bvh_build_validate(rt_context* ctx, uint64_t n, const float* boxes, uint32_t* n_nodes, uint32_t* depth, uint32_t* max_stack,
+                          double* build_ms);
+
 /* Measurement aid, no reference counterpart: runs a gather of whole 64-byte records (the BVH node
  * access pattern) over a table of table_bytes and reports the bytes it loaded, so that rocprofv3's
  * FETCH_SIZE can be calibrated for this pattern (tools/calib_fetch.py). */

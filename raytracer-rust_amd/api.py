@@ -327,6 +327,20 @@ class Context:
     def stats_reset(self):
         self._check(self._L.rt_stats_reset(self._h))
 
+    def set_bvh_builder(self, builder):
+        """'host' (binned SAH, the default) or 'gpu' (linear BVH built on the device) for the next upload."""
+        code = {"host": 0, "gpu": 1}.get(builder, builder)
+        self._check(self._L.rt_context_set_bvh_builder(self._h, int(code)))
+
+    def bvh_build_validate(self, boxes):
+        """Builds a BVH over boxes (n x 6 float32: min xyz, max xyz) with the context's builder and
+        checks it on the CPU; returns dict(nodes, depth, max_stack, build_ms)."""
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        nn, dd, ms = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        t = C.c_double(0.0)
+        self._check(self._L.rt_bvh_build_validate(self._h, b.shape[0], b.ctypes.data, C.byref(nn), C.byref(dd), C.byref(ms), C.byref(t)))
+        return dict(nodes=nn.value, depth=dd.value, max_stack=ms.value, build_ms=t.value)
+
 
 def write_png(path, rgb8):
     L = _lib.load_library()

@@ -5,7 +5,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <limits>
 #include <thread>
 
@@ -13,7 +16,7 @@ namespace rtamd {
 namespace {
 
 constexpr int kBins = 16;
-static uint32_t kMaxLeaf = 2;           // primitives per leaf (the leaf encoding allows 8)
+static uint32_t kMaxLeaf = MAX_LEAF_PRIMS;           // primitives per leaf (the leaf encoding allows 8)
 constexpr uint32_t kMedianDepth = 40;   // beyond this depth fall back to median splits (bounds the depth)
 
 struct Box {
@@ -161,8 +164,13 @@ void encode_node(GpuNode& g, const Box& node_box, const Box* child_boxes, const 
             if (i < n_children) {
                 double l = std::floor(((double)child_boxes[i].mn[k] - (double)g.p[k]) / scale[k]);
                 double h = std::ceil(((double)child_boxes[i].mx[k] - (double)g.p[k]) / scale[k]);
-                lo = (uint32_t)std::min(255.0, std::max(0.0, l));
-                hi = (uint32_t)std::min(255.0, std::max(0.0, h));
+                l = std::min(255.0, std::max(0.0, l));
+                h = std::min(255.0, std::max(0.0, h));
+                // containment is what matters: check the decoded planes themselves (q * 2^e is exact)
+                while (l > 0.0 && (double)g.p[k] + l * scale[k] > (double)child_boxes[i].mn[k]) l -= 1.0;
+                while (h < 255.0 && (double)g.p[k] + h * scale[k] < (double)child_boxes[i].mx[k]) h += 1.0;
+                lo = (uint32_t)l;
+                hi = (uint32_t)h;
             }
             qlo[k] |= lo << (8 * i);
             qhi[k] |= hi << (8 * i);
@@ -300,6 +308,89 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
         out.nodes[(size_t)it.gpu] = g;
     }
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Checks what the closest-hit kernel relies on: every primitive is in exactly one leaf, every
+// (decoded, quantised) child box contains all the boxes of its subtree, the stack bound holds.
+// Throws std::runtime_error with the first violation.
+namespace {
+[[noreturn]] void raise(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw std::runtime_error(buf);
+}
+}  // namespace
+void validate_bvh(const Bvh& bvh, const std::vector<PrimBox>& pb) {
+    const uint64_t n = pb.size();
+    if (n == 0) return;
+    if (bvh.nodes.empty()) raise("no nodes for %llu primitives", (unsigned long long)n);
+    if (bvh.order.size() != n) raise("order has %zu entries for %llu primitives", bvh.order.size(), (unsigned long long)n);
+    std::vector<uint8_t> seen(n, 0);
+    struct Item { int32_t node; uint32_t depth; uint32_t pending; };
+    // returns the union of the subtree's primitive boxes; checks containment on the way up
+    struct Ext { float mn[3], mx[3]; };
+    std::vector<Ext> ext(bvh.nodes.size());
+    std::vector<char> done(bvh.nodes.size(), 0);
+    std::vector<int32_t> st{0};
+    uint32_t worst_stack = 1;
+    std::vector<uint32_t> pend(bvh.nodes.size(), 0);
+    pend[0] = 1;
+    while (!st.empty()) {
+        int32_t x = st.back();
+        const GpuNode& g = bvh.nodes[(size_t)x];
+        int nchild = 0;
+        for (int c = 0; c < 4; ++c) if (g.child[c] != CHILD_EMPTY) nchild++;
+        if (!done[x]) {
+            done[x] = 1;
+            bool pushed = false;
+            worst_stack = std::max(worst_stack, pend[x] + (uint32_t)(nchild - 1));
+            for (int c = 0; c < 4; ++c)
+                if (g.child[c] != CHILD_EMPTY && g.child[c] >= 0) {
+                    if ((size_t)g.child[c] >= bvh.nodes.size()) raise("node %d: child index out of range", x);
+                    pend[(size_t)g.child[c]] = pend[x] + (uint32_t)(nchild - 1);
+                    st.push_back(g.child[c]); pushed = true;
+                }
+            if (pushed) continue;
+        }
+        st.pop_back();
+        Ext e;
+        for (int k = 0; k < 3; ++k) { e.mn[k] = INFINITY; e.mx[k] = -INFINITY; }
+        const uint32_t ex[3] = {g.exps & 0xFFu, (g.exps >> 8) & 0xFFu, (g.exps >> 16) & 0xFFu};
+        const uint32_t qlo[3] = {g.qlo[0], g.qlo[1], g.qlo[2]}, qhi[3] = {g.qhi_x, g.qhi_y, g.qhi_z};
+        for (int c = 0; c < 4; ++c) {
+            if (g.child[c] == CHILD_EMPTY) continue;
+            Ext sub;
+            for (int k = 0; k < 3; ++k) { sub.mn[k] = INFINITY; sub.mx[k] = -INFINITY; }
+            if (g.child[c] >= 0) sub = ext[(size_t)g.child[c]];
+            else {
+                uint32_t code = (uint32_t)~g.child[c], first = code >> 3, count = (code & 7u) + 1u;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    if (i >= n) raise("node %d: leaf range out of bounds", x);
+                    uint32_t prim = bvh.order[i];
+                    if (prim >= n || seen[prim]) raise("primitive %u referenced twice or out of range", prim);
+                    seen[prim] = 1;
+                    for (int k = 0; k < 3; ++k) { sub.mn[k] = std::min(sub.mn[k], pb[prim].mn[k]); sub.mx[k] = std::max(sub.mx[k], pb[prim].mx[k]); }
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                uint32_t bits = ex[k] << 23;
+                float scale;
+                memcpy(&scale, &bits, 4);
+                // decoded exactly (q * 2^e is exact, the sum is evaluated in double here)
+                double lo = (double)g.p[k] + (double)((qlo[k] >> (8 * c)) & 0xFFu) * (double)scale;
+                double hi = (double)g.p[k] + (double)((qhi[k] >> (8 * c)) & 0xFFu) * (double)scale;
+                if (lo > (double)sub.mn[k] || hi < (double)sub.mx[k])
+                    raise("node %d child %d (code %d) axis %d: decoded box [%g,%g] does not contain [%g,%g]", x, c, g.child[c], k, lo, hi, sub.mn[k], sub.mx[k]);
+                e.mn[k] = std::min(e.mn[k], sub.mn[k]); e.mx[k] = std::max(e.mx[k], sub.mx[k]);
+            }
+        }
+        ext[(size_t)x] = e;
+    }
+    for (uint64_t i = 0; i < n; ++i) if (!seen[i]) raise("primitive %llu is in no leaf", (unsigned long long)i);
+    if (worst_stack > bvh.max_stack) raise("max_stack %u is below the real bound %u", bvh.max_stack, worst_stack);
 }
 
 }  // namespace rtamd

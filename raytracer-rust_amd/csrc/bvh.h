@@ -5,6 +5,7 @@
 // object scan (/root/reference/src/raytracer/scene/scene.rs:35-52).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace rtamd {
@@ -24,6 +25,7 @@ struct PrimBox {
 // child box = [p + qlo * scale, p + qhi * scale] (qlo rounded down, qhi rounded up: conservative).
 // The kernel bounds its own rounding error per node, so no further padding is needed.
 constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
+constexpr uint32_t MAX_LEAF_PRIMS = 2;   // primitives per leaf both builders produce (the leaf code allows 8)
 struct GpuNode {
     float p[3];
     uint32_t exps;
@@ -43,5 +45,13 @@ struct Bvh {
 
 // Boxes must already be conservative for the f32 data the kernel tests.
 void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads = 0);
+
+// Throws std::runtime_error unless the tree is one the closest-hit kernel can traverse correctly
+// (see bvh.cpp).  Used by rt_host_bvh_validate and by the GPU builder's test entry.
+void validate_bvh(const Bvh& bvh, const std::vector<PrimBox>& boxes);
+
+// GPU builder (bvh_gpu.hip): same contract as build_bvh, on the current device; stream is a hipStream_t.
+// Returns 0 or fills err.
+int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std::string& err);
 
 }  // namespace rtamd

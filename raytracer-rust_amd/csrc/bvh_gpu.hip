@@ -1,0 +1,323 @@
+// GPU BVH builder: the same 4-wide quantised nodes as bvh.cpp, built on the device in
+// milliseconds for scenes that change every frame.  Linear BVH: Morton codes of the primitive
+// centroids, one radix sort (rocPRIM), the binary radix tree of Karras 2012 (one thread per internal
+// node), boxes bottom-up (one thread per leaf, the second arrival at a node continues), then a
+// level-by-level collapse into 4-wide nodes with the greedy largest-area rule of bvh.cpp.
+// The tree is of lower quality than the host's binned-SAH tree (more nodes per ray): it is an option
+// (rt_context_set_bvh_builder), not the default.  No reference counterpart: the reference has one
+// AABB per mesh (/root/reference/src/raytracer/scene/mesh.rs:318-326).
+#include <hip/hip_runtime.h>
+#include <string.h>   // rocprim's texture_cache_iterator.hpp uses memset without including it
+#include <cstring>
+using std::memset;
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh.h"
+
+namespace rtamd {
+namespace {
+
+#define GPU_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); goto fail; } \
+    } while (0)
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// key = 30-bit Morton code of the centroid << 32 | primitive index (unique keys, stable order)
+__global__ __launch_bounds__(256) void k_lbvh_keys(const PrimBox* __restrict__ boxes, uint32_t n, float lx, float ly, float lz, float sx,
+                                                    float sy, float sz, unsigned long long* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PrimBox b = boxes[i];
+    const float cx = (0.5f * (b.mn[0] + b.mx[0]) - lx) * sx, cy = (0.5f * (b.mn[1] + b.mx[1]) - ly) * sy, cz = (0.5f * (b.mn[2] + b.mx[2]) - lz) * sz;
+    const uint32_t qx = (uint32_t)fminf(fmaxf(cx, 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf(cy, 0.f), 1023.f), qz = (uint32_t)fminf(fmaxf(cz, 0.f), 1023.f);
+    const uint32_t m = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
+    keys[i] = ((unsigned long long)m << 32) | i;
+}
+
+// Binary radix tree over the sorted keys.  Child encoding: >= 0 internal node, < 0: ~(leaf position).
+struct Tree {
+    int* left;        // [n-1]
+    int* right;       // [n-1]
+    int* parent;      // [n-1] parent of internal node (root: -1)
+    int* leaf_parent; // [n]
+    uint32_t* first;  // [n-1] range of sorted positions covered
+    uint32_t* last;
+    float* box;       // [n-1][6]
+    uint32_t* flag;   // [n-1] arrivals
+};
+
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ k, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(k[i] ^ k[j]));
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_tree(const unsigned long long* __restrict__ keys, int n, Tree t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int s = lmax >> 1; s >= 1; s >>= 1)
+        if (delta(keys, n, i, i + (l + s) * d) > dmin) l += s;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int tt = (l + 1) >> 1;; tt = (tt + 1) >> 1) {
+        if (delta(keys, n, i, i + (s + tt) * d) > dnode) s += tt;
+        if (tt <= 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int lc = (lo == gamma) ? ~gamma : gamma;
+    const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    t.left[i] = lc; t.right[i] = rc;
+    t.first[i] = (uint32_t)lo; t.last[i] = (uint32_t)hi;
+    if (lc >= 0) t.parent[lc] = i; else t.leaf_parent[~lc] = i;
+    if (rc >= 0) t.parent[rc] = i; else t.leaf_parent[~rc] = i;
+    if (i == 0) t.parent[0] = -1;
+}
+
+__device__ __forceinline__ void load_box(const Tree& t, const PrimBox* __restrict__ boxes, const unsigned long long* __restrict__ keys, int c, float b[6]) {
+    if (c < 0) {
+        const PrimBox p = boxes[(uint32_t)(keys[~c] & 0xFFFFFFFFull)];
+        b[0] = p.mn[0]; b[1] = p.mn[1]; b[2] = p.mn[2]; b[3] = p.mx[0]; b[4] = p.mx[1]; b[5] = p.mx[2];
+    } else {
+        // written by another thread before its (fenced) arrival at our common parent; this thread has
+        // passed an agent-scope fence since (k_lbvh_boxes), or reads in a later kernel (k_lbvh_collapse)
+        for (int k = 0; k < 6; ++k) b[k] = t.box[6 * (size_t)c + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_boxes(const unsigned long long* __restrict__ keys, const PrimBox* __restrict__ boxes, int n, Tree t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = t.leaf_parent[i];
+    // at most n-1 steps: every internal node is completed exactly once
+    for (int guard = 0; guard < n && p >= 0; ++guard) {
+        __threadfence();
+        if (atomicAdd(&t.flag[p], 1u) == 0u) return;       // first arrival: the sibling subtree is not done yet
+        __threadfence();
+        float a[6], b[6];
+        load_box(t, boxes, keys, t.left[p], a);
+        load_box(t, boxes, keys, t.right[p], b);
+        for (int k = 0; k < 3; ++k) {
+            t.box[6 * (size_t)p + k] = fminf(a[k], b[k]);
+            t.box[6 * (size_t)p + 3 + k] = fmaxf(a[3 + k], b[3 + k]);
+        }
+        p = t.parent[p];
+    }
+}
+
+struct Item { int node; uint32_t wide; };
+
+__device__ __forceinline__ uint32_t kid_size(const Tree& t, int c) { return c < 0 ? 1u : t.last[c] - t.first[c] + 1u; }
+
+// One thread per wide node of the current level.
+__global__ __launch_bounds__(128) void k_lbvh_collapse(const unsigned long long* __restrict__ keys, const PrimBox* __restrict__ boxes, Tree t,
+                                                        const Item* __restrict__ items, uint32_t n_items, Item* __restrict__ next,
+                                                        uint32_t* __restrict__ counters /* [0] next count, [1] wide count, [2] overflow */,
+                                                        uint32_t max_wide, GpuNode* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const Item it = items[i];
+    int kids[4];
+    float kb[4][6];
+    int nk = 2;
+    kids[0] = t.left[it.node]; kids[1] = t.right[it.node];
+    load_box(t, boxes, keys, kids[0], kb[0]);
+    load_box(t, boxes, keys, kids[1], kb[1]);
+    while (nk < 4) {
+        int best = -1; float area = -1.f;
+        for (int k = 0; k < nk; ++k) {
+            if (kids[k] < 0 || kid_size(t, kids[k]) <= MAX_LEAF_PRIMS) continue;
+            const float dx = kb[k][3] - kb[k][0], dy = kb[k][4] - kb[k][1], dz = kb[k][5] - kb[k][2];
+            const float a = dx * dy + dy * dz + dz * dx;
+            if (a > area) { area = a; best = k; }
+        }
+        if (best < 0) break;
+        const int c = kids[best];
+        kids[best] = t.left[c]; kids[nk] = t.right[c];
+        load_box(t, boxes, keys, kids[best], kb[best]);
+        load_box(t, boxes, keys, kids[nk], kb[nk]);
+        nk++;
+    }
+    // node box and scales (bvh.cpp encode_node)
+    float nb[6];
+    for (int k = 0; k < 6; ++k) nb[k] = t.box[6 * (size_t)it.node + k];
+    GpuNode g;
+    uint32_t e8[3];
+    double scale[3];
+    for (int k = 0; k < 3; ++k) {
+        g.p[k] = nb[k];
+        double ext = (double)nb[3 + k] - (double)nb[k];
+        if (!(ext > 0.0)) ext = 0.0;
+        int e = (ext > 0.0) ? (int)ceil(log2(ext / 255.0)) : -126;
+        while (e < 127 && ldexp(255.0, e) < ext) e++;
+        e = min(127, max(-126, e));
+        e8[k] = (uint32_t)(e + 127);
+        scale[k] = ldexp(1.0, e);
+    }
+    g.exps = e8[0] | (e8[1] << 8) | (e8[2] << 16);
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+        int32_t code = CHILD_EMPTY;
+        if (c < nk) {
+            const int kid = kids[c];
+            const uint32_t size = kid_size(t, kid);
+            if (kid >= 0 && size > MAX_LEAF_PRIMS) {
+                const uint32_t w = atomicAdd(&counters[1], 1u);
+                if (w < max_wide) {
+                    const uint32_t q = atomicAdd(&counters[0], 1u);
+                    next[q] = Item{kid, w};
+                    code = (int32_t)w;
+                } else {
+                    atomicAdd(&counters[2], 1u);      // cannot happen (max_wide = n); keeps the tree consistent if it did
+                }
+            } else {
+                const uint32_t first = kid < 0 ? (uint32_t)~kid : t.first[kid];
+                code = ~(int32_t)((first << 3) | (size - 1u));
+            }
+        }
+        g.child[c] = code;
+        for (int k = 0; k < 3; ++k) {
+            uint32_t lo = 255, hi = 0;
+            if (c < nk && code != CHILD_EMPTY) {
+                double l = floor(((double)kb[c][k] - (double)g.p[k]) / scale[k]);
+                double h = ceil(((double)kb[c][3 + k] - (double)g.p[k]) / scale[k]);
+                l = fmin(255.0, fmax(0.0, l));
+                h = fmin(255.0, fmax(0.0, h));
+                // containment is what matters: check the decoded planes themselves (q * 2^e is exact)
+                while (l > 0.0 && (double)g.p[k] + l * scale[k] > (double)kb[c][k]) l -= 1.0;
+                while (h < 255.0 && (double)g.p[k] + h * scale[k] < (double)kb[c][3 + k]) h += 1.0;
+                lo = (uint32_t)l;
+                hi = (uint32_t)h;
+            }
+            qlo[k] |= lo << (8 * c);
+            qhi[k] |= hi << (8 * c);
+        }
+    }
+    g.qlo[0] = qlo[0]; g.qlo[1] = qlo[1]; g.qlo[2] = qlo[2];
+    g.qhi_x = qhi[0]; g.qhi_y = qhi[1]; g.qhi_z = qhi[2];
+    g.pad0 = 0; g.pad1 = 0;
+    nodes[it.wide] = g;
+}
+
+}  // namespace
+
+// Builds `out` (same contract as build_bvh) on the current device.  Returns 0 or fills err.
+// Small inputs go to the host builder.
+int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std::string& err) {
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t n = (uint32_t)boxes.size();
+    err.clear();
+    if (n < 1024u) { build_bvh(boxes, out); return 0; }
+    auto t0 = std::chrono::steady_clock::now();
+    // centroid bounds on the host (one pass over data that is on the host anyway)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float c = 0.5f * (boxes[i].mn[k] + boxes[i].mx[k]);
+            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
+        }
+    float sc[3];
+    for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 1024.f / (hi[k] - lo[k]) : 0.f;
+
+    PrimBox* d_boxes = nullptr;
+    unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
+    void* d_temp = nullptr;
+    Tree t{};
+    Item* d_items[2] = {nullptr, nullptr};
+    uint32_t* d_counters = nullptr;
+    GpuNode* d_nodes = nullptr;
+    size_t temp_bytes = 0;
+    const uint32_t max_wide = n;
+    uint32_t levels = 0, n_items = 1, wide_count = 1;
+    std::vector<unsigned long long> h_sorted;
+    const uint32_t blocks = (n + 255u) / 256u;
+
+    GPU_TRY(hipMalloc((void**)&d_boxes, (size_t)n * sizeof(PrimBox)));
+    GPU_TRY(hipMalloc((void**)&d_keys, (size_t)n * 8));
+    GPU_TRY(hipMalloc((void**)&d_sorted, (size_t)n * 8));
+    GPU_TRY(hipMalloc((void**)&t.left, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.right, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.parent, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.leaf_parent, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.first, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.last, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.box, (size_t)n * 24));
+    GPU_TRY(hipMalloc((void**)&t.flag, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&d_items[0], (size_t)n * sizeof(Item)));
+    GPU_TRY(hipMalloc((void**)&d_items[1], (size_t)n * sizeof(Item)));
+    GPU_TRY(hipMalloc((void**)&d_counters, 16));
+    GPU_TRY(hipMalloc((void**)&d_nodes, (size_t)max_wide * sizeof(GpuNode)));
+    GPU_TRY(hipMemcpyAsync(d_boxes, boxes.data(), (size_t)n * sizeof(PrimBox), hipMemcpyHostToDevice, st));
+    GPU_TRY(hipMemsetAsync(t.flag, 0, (size_t)n * 4, st));
+    GPU_TRY(hipMemsetAsync(t.parent, 0xFF, (size_t)n * 4, st));
+    GPU_TRY(hipMemsetAsync(t.leaf_parent, 0xFF, (size_t)n * 4, st));
+
+    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks), dim3(256), 0, st, d_boxes, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_keys);
+    GPU_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, d_keys, d_sorted, (size_t)n, 0u, 64u, st));
+    GPU_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
+    GPU_TRY(rocprim::radix_sort_keys(d_temp, temp_bytes, d_keys, d_sorted, (size_t)n, 0u, 64u, st));
+    hipLaunchKernelGGL(k_lbvh_tree, dim3(blocks), dim3(256), 0, st, d_sorted, (int)n, t);
+    hipLaunchKernelGGL(k_lbvh_boxes, dim3(blocks), dim3(256), 0, st, d_sorted, d_boxes, (int)n, t);
+    GPU_TRY(hipGetLastError());
+
+    // collapse, one level per launch (the root, binary node 0, is wide node 0)
+    {
+        const Item root{0, 0u};
+        const uint32_t init[4] = {0u, 1u, 0u, 0u};
+        GPU_TRY(hipMemcpyAsync(d_items[0], &root, sizeof(root), hipMemcpyHostToDevice, st));
+        GPU_TRY(hipMemcpyAsync(d_counters, init, sizeof(init), hipMemcpyHostToDevice, st));
+        GPU_TRY(hipStreamSynchronize(st));
+    }
+    while (n_items > 0) {
+        if (++levels > 4096u) { err = "GPU BVH: collapse does not terminate"; goto fail; }
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3((n_items + 127u) / 128u), dim3(128), 0, st, d_sorted, d_boxes, t, d_items[(levels - 1) & 1],
+                           n_items, d_items[levels & 1], d_counters, max_wide, d_nodes);
+        uint32_t c[4];
+        GPU_TRY(hipMemcpyAsync(c, d_counters, sizeof(c), hipMemcpyDeviceToHost, st));
+        GPU_TRY(hipStreamSynchronize(st));
+        if (c[2]) { err = "GPU BVH: node pool overflow"; goto fail; }
+        n_items = c[0]; wide_count = c[1];
+        if (n_items > n) { err = "GPU BVH: queue overflow"; goto fail; }
+        GPU_TRY(hipMemsetAsync(d_counters, 0, 4, st));     // next-level count
+    }
+    out.nodes.resize(wide_count);
+    h_sorted.resize(n);
+    GPU_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)wide_count * sizeof(GpuNode), hipMemcpyDeviceToHost, st));
+    GPU_TRY(hipMemcpyAsync(h_sorted.data(), d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GPU_TRY(hipStreamSynchronize(st));
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out.order[i] = (uint32_t)(h_sorted[i] & 0xFFFFFFFFull);
+    out.max_depth = levels;
+    out.max_stack = 1u + 3u * levels;     // up to three siblings wait per level, plus the sentinel
+    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    err.clear();
+fail:
+    (void)hipFree(d_boxes); (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_temp);
+    (void)hipFree(t.left); (void)hipFree(t.right); (void)hipFree(t.parent); (void)hipFree(t.leaf_parent);
+    (void)hipFree(t.first); (void)hipFree(t.last); (void)hipFree(t.box); (void)hipFree(t.flag);
+    (void)hipFree(d_items[0]); (void)hipFree(d_items[1]); (void)hipFree(d_counters); (void)hipFree(d_nodes);
+    return err.empty() ? 0 : 1;
+}
+
+}  // namespace rtamd

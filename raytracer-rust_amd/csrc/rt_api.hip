@@ -35,6 +35,7 @@ struct rt_context {
     bool have_scene = false;
     DevScene sc{};
     std::vector<void*> scene_allocs;
+    int bvh_builder = 0;      // 0: host binned SAH (bvh.cpp), 1: GPU LBVH (bvh_gpu.hip)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_prims = 0;
     double bvh_build_ms = 0;
 
@@ -280,7 +281,12 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
     std::vector<PrimBox> bvh_boxes(bvh_src.size());
     for (size_t i = 0; i < bvh_src.size(); ++i) bvh_boxes[i] = boxes[bvh_src[i]];
     Bvh bvh;
-    build_bvh(bvh_boxes, bvh);
+    if (ctx->bvh_builder == 1) {
+        std::string berr;
+        if (build_bvh_gpu(bvh_boxes, bvh, ctx->own_stream, berr)) return fail(ctx, "GPU BVH build failed: %s", berr.c_str());
+    } else {
+        build_bvh(bvh_boxes, bvh);
+    }
     const uint32_t n_leaf_prims = (uint32_t)bvh_src.size();
 
     // ---- records: BVH primitives in leaf order, then the big spheres
@@ -579,6 +585,41 @@ int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, i
     } while (0);
     (void)hipFree(d_obj); (void)hipFree(d_tri); (void)hipFree(d_t); (void)hipFree(d_n);
     return rc;
+}
+
+int rt_context_set_bvh_builder(rt_context* ctx, int builder) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (builder != 0 && builder != 1) return fail(ctx, "unknown BVH builder %d (0: host SAH, 1: GPU LBVH)", builder);
+    ctx->bvh_builder = builder;
+    return 0;
+}
+
+int rt_bvh_build_validate(rt_context* ctx, uint64_t n, const float* boxes, uint32_t* n_nodes, uint32_t* depth, uint32_t* max_stack, double* build_ms) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (!boxes && n) return fail(ctx, "boxes is NULL");
+    if (n > 0x7FFFFFF0ull) return fail(ctx, "too many primitives");
+    DeviceGuard g(ctx->device);
+    std::vector<PrimBox> pb(n);
+    for (uint64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { pb[i].mn[k] = boxes[6 * i + k]; pb[i].mx[k] = boxes[6 * i + 3 + k]; }
+    Bvh bvh;
+    if (ctx->bvh_builder == 1) {
+        std::string berr;
+        if (build_bvh_gpu(pb, bvh, ctx->own_stream, berr)) return fail(ctx, "GPU BVH build failed: %s", berr.c_str());
+    } else {
+        build_bvh(pb, bvh);
+    }
+    if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
+    if (depth) *depth = bvh.max_depth;
+    if (max_stack) *max_stack = bvh.max_stack;
+    if (build_ms) *build_ms = bvh.build_ms;
+    try {
+        if (n && bvh.order.size() != n) return fail(ctx, "order has %zu entries for %llu primitives", bvh.order.size(), (unsigned long long)n);
+        validate_bvh(bvh, pb);
+    } catch (const std::exception& e) {
+        return fail(ctx, "%s", e.what());
+    }
+    return 0;
 }
 
 int rt_get_stats(rt_context* ctx, rt_stats* out) {

@@ -812,70 +812,7 @@ int rt_host_bvh_validate(uint64_t n, const float* boxes, uint32_t* n_nodes, uint
         if (depth) *depth = bvh.max_depth;
         if (max_stack) *max_stack = bvh.max_stack;
         if (n == 0) return 0;
-        if (bvh.order.size() != n) raise("order has %zu entries for %llu primitives", bvh.order.size(), (unsigned long long)n);
-        std::vector<uint8_t> seen(n, 0);
-        struct Item { int32_t node; uint32_t depth; uint32_t pending; };
-        // returns the union of the subtree's primitive boxes; checks containment on the way up
-        struct Ext { float mn[3], mx[3]; };
-        std::vector<Ext> ext(bvh.nodes.size());
-        std::vector<char> done(bvh.nodes.size(), 0);
-        std::vector<int32_t> st{0};
-        uint32_t worst_stack = 1;
-        std::vector<uint32_t> pend(bvh.nodes.size(), 0);
-        pend[0] = 1;
-        while (!st.empty()) {
-            int32_t x = st.back();
-            const rtamd::GpuNode& g = bvh.nodes[(size_t)x];
-            int nchild = 0;
-            for (int c = 0; c < 4; ++c) if (g.child[c] != rtamd::CHILD_EMPTY) nchild++;
-            if (!done[x]) {
-                done[x] = 1;
-                bool pushed = false;
-                worst_stack = std::max(worst_stack, pend[x] + (uint32_t)(nchild - 1));
-                for (int c = 0; c < 4; ++c)
-                    if (g.child[c] != rtamd::CHILD_EMPTY && g.child[c] >= 0) {
-                        if ((size_t)g.child[c] >= bvh.nodes.size()) raise("node %d: child index out of range", x);
-                        pend[(size_t)g.child[c]] = pend[x] + (uint32_t)(nchild - 1);
-                        st.push_back(g.child[c]); pushed = true;
-                    }
-                if (pushed) continue;
-            }
-            st.pop_back();
-            Ext e;
-            for (int k = 0; k < 3; ++k) { e.mn[k] = INFINITY; e.mx[k] = -INFINITY; }
-            const uint32_t ex[3] = {g.exps & 0xFFu, (g.exps >> 8) & 0xFFu, (g.exps >> 16) & 0xFFu};
-            const uint32_t qlo[3] = {g.qlo[0], g.qlo[1], g.qlo[2]}, qhi[3] = {g.qhi_x, g.qhi_y, g.qhi_z};
-            for (int c = 0; c < 4; ++c) {
-                if (g.child[c] == rtamd::CHILD_EMPTY) continue;
-                Ext sub;
-                for (int k = 0; k < 3; ++k) { sub.mn[k] = INFINITY; sub.mx[k] = -INFINITY; }
-                if (g.child[c] >= 0) sub = ext[(size_t)g.child[c]];
-                else {
-                    uint32_t code = (uint32_t)~g.child[c], first = code >> 3, count = (code & 7u) + 1u;
-                    for (uint32_t i = first; i < first + count; ++i) {
-                        if (i >= n) raise("node %d: leaf range out of bounds", x);
-                        uint32_t prim = bvh.order[i];
-                        if (prim >= n || seen[prim]) raise("primitive %u referenced twice or out of range", prim);
-                        seen[prim] = 1;
-                        for (int k = 0; k < 3; ++k) { sub.mn[k] = std::min(sub.mn[k], pb[prim].mn[k]); sub.mx[k] = std::max(sub.mx[k], pb[prim].mx[k]); }
-                    }
-                }
-                for (int k = 0; k < 3; ++k) {
-                    uint32_t bits = ex[k] << 23;
-                    float scale;
-                    memcpy(&scale, &bits, 4);
-                    // decoded exactly (q * 2^e is exact, the sum is evaluated in double here)
-                    double lo = (double)g.p[k] + (double)((qlo[k] >> (8 * c)) & 0xFFu) * (double)scale;
-                    double hi = (double)g.p[k] + (double)((qhi[k] >> (8 * c)) & 0xFFu) * (double)scale;
-                    if (lo > (double)sub.mn[k] || hi < (double)sub.mx[k])
-                        raise("node %d child %d axis %d: decoded box [%g,%g] does not contain [%g,%g]", x, c, k, lo, hi, sub.mn[k], sub.mx[k]);
-                    e.mn[k] = std::min(e.mn[k], sub.mn[k]); e.mx[k] = std::max(e.mx[k], sub.mx[k]);
-                }
-            }
-            ext[(size_t)x] = e;
-        }
-        for (uint64_t i = 0; i < n; ++i) if (!seen[i]) raise("primitive %llu is in no leaf", (unsigned long long)i);
-        if (worst_stack > bvh.max_stack) raise("max_stack %u is below the real bound %u", bvh.max_stack, worst_stack);
+        rtamd::validate_bvh(bvh, pb);
         return 0;
     } catch (const std::exception& e) {
         set_err(err, err_len, e.what());

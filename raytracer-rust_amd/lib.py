@@ -52,7 +52,7 @@ class StatsC(C.Structure):
 # every symbol the headers declare (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_render_accumulate", "rt_resolve",
-    "rt_render_image", "rt_primary_hits", "rt_get_stats", "rt_stats_reset", "rt_debug_gather",
+    "rt_render_image", "rt_primary_hits", "rt_get_stats", "rt_stats_reset", "rt_debug_gather", "rt_context_set_bvh_builder", "rt_bvh_build_validate",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_desc", "rt_host_scene_num_objects", "rt_host_scene_object_kind",
     "rt_host_ssaa_parse", "rt_host_camera", "rt_host_write_png", "rt_host_read_png", "rt_host_free", "rt_host_compute_image", "rt_host_bvh_validate",
 ]
@@ -101,6 +101,10 @@ def load_library():
     L.rt_get_stats.restype = C.c_int
     L.rt_get_stats.argtypes = [vp, C.POINTER(StatsC)]
     L.rt_debug_gather.restype = C.c_int
+    L.rt_context_set_bvh_builder.restype = C.c_int
+    L.rt_context_set_bvh_builder.argtypes = [vp, C.c_int]
+    L.rt_bvh_build_validate.restype = C.c_int
+    L.rt_bvh_build_validate.argtypes = [vp, u64, C.c_void_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(dbl)]
     L.rt_debug_gather.argtypes = [vp, u64, u32, C.POINTER(dbl)]
     L.rt_stats_reset.restype = C.c_int
     L.rt_stats_reset.argtypes = [vp]
