@@ -101,4 +101,6 @@ extern "C" {
     pub fn rt_get_stats(ctx: *mut rt_context, out: *mut rt_stats) -> c_int;
     pub fn rt_stats_reset(ctx: *mut rt_context) -> c_int;
     pub fn rt_debug_gather(ctx: *mut rt_context, table_bytes: u64, iters: u32, bytes_loaded: *mut f64) -> c_int;
+    pub fn rt_context_set_bvh_builder(ctx: *mut rt_context, builder: c_int) -> c_int;
+    pub fn rt_bvh_build_validate(ctx: *mut rt_context, n: u64, boxes: *const f32, n_nodes: *mut u32, depth: *mut u32, max_stack: *mut u32, build_ms: *mut f64) -> c_int;
 }
