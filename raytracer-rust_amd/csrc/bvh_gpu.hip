@@ -1,5 +1,5 @@
 // GPU BVH builder: the same 4-wide quantised nodes as bvh.cpp, built on the device in
-// milliseconds for scenes that change every frame.  Linear BVH: Morton codes of the primitive
+// milliseconds for scenes that change every frame.  Linear BVH: 63-bit Morton codes of the primitive
 // centroids, one radix sort (rocPRIM), the binary radix tree of Karras 2012 (one thread per internal
 // node), boxes bottom-up (one thread per leaf, the second arrival at a node continues), then a
 // level-by-level collapse into 4-wide nodes with the greedy largest-area rule of bvh.cpp.
@@ -30,24 +30,28 @@ namespace {
         if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); goto fail; } \
     } while (0)
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+__device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bits -> every third bit
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
 }
 
-// key = 30-bit Morton code of the centroid << 32 | primitive index (unique keys, stable order)
+// key = 63-bit Morton code of the centroid (21 bits per axis); value = primitive index.  Equal keys are
+// told apart by their sorted position (delta below), so the tree is well defined for any input.
 __global__ __launch_bounds__(256) void k_lbvh_keys(const PrimBox* __restrict__ boxes, uint32_t n, float lx, float ly, float lz, float sx,
-                                                    float sy, float sz, unsigned long long* __restrict__ keys) {
+                                                    float sy, float sz, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const PrimBox b = boxes[i];
     const float cx = (0.5f * (b.mn[0] + b.mx[0]) - lx) * sx, cy = (0.5f * (b.mn[1] + b.mx[1]) - ly) * sy, cz = (0.5f * (b.mn[2] + b.mx[2]) - lz) * sz;
-    const uint32_t qx = (uint32_t)fminf(fmaxf(cx, 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf(cy, 0.f), 1023.f), qz = (uint32_t)fminf(fmaxf(cz, 0.f), 1023.f);
-    const uint32_t m = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
-    keys[i] = ((unsigned long long)m << 32) | i;
+    const float top = 2097151.f;
+    const uint32_t qx = (uint32_t)fminf(fmaxf(cx, 0.f), top), qy = (uint32_t)fminf(fmaxf(cy, 0.f), top), qz = (uint32_t)fminf(fmaxf(cz, 0.f), top);
+    keys[i] = (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
+    vals[i] = i;
 }
 
 // Binary radix tree over the sorted keys.  Child encoding: >= 0 internal node, < 0: ~(leaf position).
@@ -64,7 +68,8 @@ struct Tree {
 
 __device__ __forceinline__ int delta(const unsigned long long* __restrict__ k, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long)(k[i] ^ k[j]));
+    const unsigned long long x = k[i] ^ k[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);     // equal codes: the sorted positions decide
 }
 
 __global__ __launch_bounds__(256) void k_lbvh_tree(const unsigned long long* __restrict__ keys, int n, Tree t) {
@@ -95,9 +100,9 @@ __global__ __launch_bounds__(256) void k_lbvh_tree(const unsigned long long* __r
     if (i == 0) t.parent[0] = -1;
 }
 
-__device__ __forceinline__ void load_box(const Tree& t, const PrimBox* __restrict__ boxes, const unsigned long long* __restrict__ keys, int c, float b[6]) {
+__device__ __forceinline__ void load_box(const Tree& t, const PrimBox* __restrict__ boxes, const uint32_t* __restrict__ vals, int c, float b[6]) {
     if (c < 0) {
-        const PrimBox p = boxes[(uint32_t)(keys[~c] & 0xFFFFFFFFull)];
+        const PrimBox p = boxes[vals[~c]];
         b[0] = p.mn[0]; b[1] = p.mn[1]; b[2] = p.mn[2]; b[3] = p.mx[0]; b[4] = p.mx[1]; b[5] = p.mx[2];
     } else {
         // written by another thread before its (fenced) arrival at our common parent; this thread has
@@ -106,7 +111,7 @@ __device__ __forceinline__ void load_box(const Tree& t, const PrimBox* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_boxes(const unsigned long long* __restrict__ keys, const PrimBox* __restrict__ boxes, int n, Tree t) {
+__global__ __launch_bounds__(256) void k_lbvh_boxes(const uint32_t* __restrict__ vals, const PrimBox* __restrict__ boxes, int n, Tree t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int p = t.leaf_parent[i];
@@ -116,8 +121,8 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const unsigned long long* __
         if (atomicAdd(&t.flag[p], 1u) == 0u) return;       // first arrival: the sibling subtree is not done yet
         __threadfence();
         float a[6], b[6];
-        load_box(t, boxes, keys, t.left[p], a);
-        load_box(t, boxes, keys, t.right[p], b);
+        load_box(t, boxes, vals, t.left[p], a);
+        load_box(t, boxes, vals, t.right[p], b);
         for (int k = 0; k < 3; ++k) {
             t.box[6 * (size_t)p + k] = fminf(a[k], b[k]);
             t.box[6 * (size_t)p + 3 + k] = fmaxf(a[3 + k], b[3 + k]);
@@ -131,7 +136,7 @@ struct Item { int node; uint32_t wide; };
 __device__ __forceinline__ uint32_t kid_size(const Tree& t, int c) { return c < 0 ? 1u : t.last[c] - t.first[c] + 1u; }
 
 // One thread per wide node of the current level.
-__global__ __launch_bounds__(128) void k_lbvh_collapse(const unsigned long long* __restrict__ keys, const PrimBox* __restrict__ boxes, Tree t,
+__global__ __launch_bounds__(128) void k_lbvh_collapse(const uint32_t* __restrict__ vals, const PrimBox* __restrict__ boxes, Tree t,
                                                         const Item* __restrict__ items, uint32_t n_items, Item* __restrict__ next,
                                                         uint32_t* __restrict__ counters /* [0] next count, [1] wide count, [2] overflow */,
                                                         uint32_t max_wide, GpuNode* __restrict__ nodes) {
@@ -142,8 +147,8 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const unsigned long long*
     float kb[4][6];
     int nk = 2;
     kids[0] = t.left[it.node]; kids[1] = t.right[it.node];
-    load_box(t, boxes, keys, kids[0], kb[0]);
-    load_box(t, boxes, keys, kids[1], kb[1]);
+    load_box(t, boxes, vals, kids[0], kb[0]);
+    load_box(t, boxes, vals, kids[1], kb[1]);
     while (nk < 4) {
         int best = -1; float area = -1.f;
         for (int k = 0; k < nk; ++k) {
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const unsigned long long*
         if (best < 0) break;
         const int c = kids[best];
         kids[best] = t.left[c]; kids[nk] = t.right[c];
-        load_box(t, boxes, keys, kids[best], kb[best]);
-        load_box(t, boxes, keys, kids[nk], kb[nk]);
+        load_box(t, boxes, vals, kids[best], kb[best]);
+        load_box(t, boxes, vals, kids[nk], kb[nk]);
         nk++;
     }
     // node box and scales (bvh.cpp encode_node)
@@ -238,10 +243,11 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
             lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
         }
     float sc[3];
-    for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 1024.f / (hi[k] - lo[k]) : 0.f;
+    for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 2097152.f / (hi[k] - lo[k]) : 0.f;
 
     PrimBox* d_boxes = nullptr;
     unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
+    uint32_t *d_vals = nullptr, *d_vsorted = nullptr;
     void* d_temp = nullptr;
     Tree t{};
     Item* d_items[2] = {nullptr, nullptr};
@@ -250,12 +256,13 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
     size_t temp_bytes = 0;
     const uint32_t max_wide = n;
     uint32_t levels = 0, n_items = 1, wide_count = 1;
-    std::vector<unsigned long long> h_sorted;
     const uint32_t blocks = (n + 255u) / 256u;
 
     GPU_TRY(hipMalloc((void**)&d_boxes, (size_t)n * sizeof(PrimBox)));
     GPU_TRY(hipMalloc((void**)&d_keys, (size_t)n * 8));
     GPU_TRY(hipMalloc((void**)&d_sorted, (size_t)n * 8));
+    GPU_TRY(hipMalloc((void**)&d_vals, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&d_vsorted, (size_t)n * 4));
     GPU_TRY(hipMalloc((void**)&t.left, (size_t)n * 4));
     GPU_TRY(hipMalloc((void**)&t.right, (size_t)n * 4));
     GPU_TRY(hipMalloc((void**)&t.parent, (size_t)n * 4));
@@ -273,12 +280,12 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
     GPU_TRY(hipMemsetAsync(t.parent, 0xFF, (size_t)n * 4, st));
     GPU_TRY(hipMemsetAsync(t.leaf_parent, 0xFF, (size_t)n * 4, st));
 
-    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks), dim3(256), 0, st, d_boxes, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_keys);
-    GPU_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, d_keys, d_sorted, (size_t)n, 0u, 64u, st));
+    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks), dim3(256), 0, st, d_boxes, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_keys, d_vals);
+    GPU_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_sorted, d_vals, d_vsorted, (size_t)n, 0u, 63u, st));
     GPU_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
-    GPU_TRY(rocprim::radix_sort_keys(d_temp, temp_bytes, d_keys, d_sorted, (size_t)n, 0u, 64u, st));
+    GPU_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_sorted, d_vals, d_vsorted, (size_t)n, 0u, 63u, st));
     hipLaunchKernelGGL(k_lbvh_tree, dim3(blocks), dim3(256), 0, st, d_sorted, (int)n, t);
-    hipLaunchKernelGGL(k_lbvh_boxes, dim3(blocks), dim3(256), 0, st, d_sorted, d_boxes, (int)n, t);
+    hipLaunchKernelGGL(k_lbvh_boxes, dim3(blocks), dim3(256), 0, st, d_vsorted, d_boxes, (int)n, t);
     GPU_TRY(hipGetLastError());
 
     // collapse, one level per launch (the root, binary node 0, is wide node 0)
@@ -291,7 +298,7 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
     }
     while (n_items > 0) {
         if (++levels > 4096u) { err = "GPU BVH: collapse does not terminate"; goto fail; }
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3((n_items + 127u) / 128u), dim3(128), 0, st, d_sorted, d_boxes, t, d_items[(levels - 1) & 1],
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3((n_items + 127u) / 128u), dim3(128), 0, st, d_vsorted, d_boxes, t, d_items[(levels - 1) & 1],
                            n_items, d_items[levels & 1], d_counters, max_wide, d_nodes);
         uint32_t c[4];
         GPU_TRY(hipMemcpyAsync(c, d_counters, sizeof(c), hipMemcpyDeviceToHost, st));
@@ -302,18 +309,16 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
         GPU_TRY(hipMemsetAsync(d_counters, 0, 4, st));     // next-level count
     }
     out.nodes.resize(wide_count);
-    h_sorted.resize(n);
     GPU_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)wide_count * sizeof(GpuNode), hipMemcpyDeviceToHost, st));
-    GPU_TRY(hipMemcpyAsync(h_sorted.data(), d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    GPU_TRY(hipStreamSynchronize(st));
     out.order.resize(n);
-    for (uint32_t i = 0; i < n; ++i) out.order[i] = (uint32_t)(h_sorted[i] & 0xFFFFFFFFull);
+    GPU_TRY(hipMemcpyAsync(out.order.data(), d_vsorted, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GPU_TRY(hipStreamSynchronize(st));
     out.max_depth = levels;
     out.max_stack = 1u + 3u * levels;     // up to three siblings wait per level, plus the sentinel
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     err.clear();
 fail:
-    (void)hipFree(d_boxes); (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_temp);
+    (void)hipFree(d_boxes); (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_vals); (void)hipFree(d_vsorted); (void)hipFree(d_temp);
     (void)hipFree(t.left); (void)hipFree(t.right); (void)hipFree(t.parent); (void)hipFree(t.leaf_parent);
     (void)hipFree(t.first); (void)hipFree(t.last); (void)hipFree(t.box); (void)hipFree(t.flag);
     (void)hipFree(d_items[0]); (void)hipFree(d_items[1]); (void)hipFree(d_counters); (void)hipFree(d_nodes);
