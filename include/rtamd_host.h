@@ -57,6 +57,13 @@ int rt_host_bvh_validate(uint64_t n, const float* boxes, uint32_t* n_nodes, uint
 int rt_host_compute_image(const char* ssaa, uint32_t depth, const char* scene_path, const char* output_path, const char* base_dir,
                           int device_id, uint64_t seed, char* err, size_t err_len);
 
+/* The same on n_devices GPUs from one process (additive flags of SURVEY 8b: --devices, --split): one
+ * context and host thread per device; split_tiles = 0 splits the N*N samples (disjoint ranges, the
+ * same RNG keys a single device would use), 1 deals the 8x8 tiles round-robin; the partial sums are
+ * added on the host in device order and resolved as raytrace.rs:144-150 / image.rs:37-43 do. */
+int rt_host_compute_image_devices(const char* ssaa, uint32_t depth, const char* scene_path, const char* output_path, const char* base_dir,
+                                  const int* device_ids, uint32_t n_devices, int split_tiles, uint64_t seed, char* err, size_t err_len);
+
 #ifdef __cplusplus
 }
 #endif

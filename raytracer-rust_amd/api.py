@@ -362,15 +362,22 @@ def read_png(path):
         L.rt_host_free(p)
 
 
-def compute_image(ssaa, depth, scene_path, output_path, base_dir=None, device=0, seed=0):
+def compute_image(ssaa, depth, scene_path, output_path, base_dir=None, device=0, seed=0, devices=None, split="spp"):
     """raytracer::compute_image (raytrace.rs:108-156): same four arguments; `ssaa` may be a
-    SuperSampling or the CLI string."""
+    SuperSampling or the CLI string.  devices=[0, 1, ...] renders on several GPUs from this process
+    (one context and host thread each; split = "spp" or "tiles")."""
     L = _lib.load_library()
     if isinstance(ssaa, SuperSampling):
         ssaa = ("jitter:%d" if ssaa.kind == "Jitter" else "grid:%d") % ssaa.resolution
     err = C.create_string_buffer(1024)
-    rc = L.rt_host_compute_image(ssaa.encode(), int(depth), os.fsencode(scene_path), os.fsencode(output_path),
-                                 os.fsencode(base_dir) if base_dir is not None else None, int(device), int(seed), err, 1024)
+    if devices is not None:
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = L.rt_host_compute_image_devices(ssaa.encode(), int(depth), os.fsencode(scene_path), os.fsencode(output_path),
+                                             os.fsencode(base_dir) if base_dir is not None else None, ids, len(devices),
+                                             1 if split == "tiles" else 0, int(seed), err, 1024)
+    else:
+        rc = L.rt_host_compute_image(ssaa.encode(), int(depth), os.fsencode(scene_path), os.fsencode(output_path),
+                                     os.fsencode(base_dir) if base_dir is not None else None, int(device), int(seed), err, 1024)
     if rc:
         msg = err.value.decode()
         if msg.startswith("error parsing ssaa argument: "):

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/rtamd_host.h"
 
@@ -15,7 +16,8 @@ static void usage(FILE* f) {
     fprintf(f, "USAGE:\n    rtamd-render [OPTIONS] --scene-path <SCENE_PATH> --output-path <OUTPUT_PATH>\n\nOPTIONS:\n"
                "    -d, --depth <DEPTH>                [default: 5]\n    -o, --output-path <OUTPUT_PATH>\n"
                "    -s, --scene-path <SCENE_PATH>\n        --ssaa <SSAA>                  [default: uniform:2]\n"
-               "        --device <ID>                  [default: 0]\n        --seed <SEED>                  [default: 0]\n"
+               "        --device <ID>                  [default: 0]\n        --devices <ID,ID,...>          several GPUs, one context each\n"
+               "        --split <spp|tiles>            how --devices share the frame [default: spp]\n        --seed <SEED>                  [default: 0]\n"
                "        --base-dir <DIR>\n    -h, --help\n");
 }
 
@@ -24,6 +26,8 @@ int main(int argc, char** argv) {
     bool have_base = false;
     long depth = 5;
     int device = 0;
+    std::vector<int> devices;      // --devices 0,1,2,...: one context per GPU
+    bool split_tiles = false;      // --split spp (default) | tiles
     unsigned long long seed = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i], v;
@@ -45,6 +49,27 @@ int main(int argc, char** argv) {
         }
         else if (is(nullptr, "--ssaa")) { value("--ssaa"); ssaa = v; }
         else if (is(nullptr, "--device")) { value("--device"); device = atoi(v.c_str()); }
+        else if (is(nullptr, "--devices")) {
+            value("--devices");
+            devices.clear();
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                size_t comma = v.find(',', pos);
+                std::string tok = v.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                char* end = nullptr;
+                long d = strtol(tok.c_str(), &end, 10);
+                if (tok.empty() || *end || d < 0) { fprintf(stderr, "error: Invalid value \"%s\" for '--devices <DEVICES>': expected a comma-separated list of GPU indices\n", v.c_str()); return 2; }
+                devices.push_back((int)d);
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+        }
+        else if (is(nullptr, "--split")) {
+            value("--split");
+            if (v == "tiles") split_tiles = true;
+            else if (v == "spp") split_tiles = false;
+            else { fprintf(stderr, "error: Invalid value \"%s\" for '--split <SPLIT>': expected spp or tiles\n", v.c_str()); return 2; }
+        }
         else if (is(nullptr, "--seed")) { value("--seed"); seed = strtoull(v.c_str(), nullptr, 10); }
         else if (is(nullptr, "--base-dir")) { value("--base-dir"); base_dir = v; have_base = true; }
         else if (a == "-h" || a == "--help") { usage(stdout); return 0; }
@@ -64,6 +89,14 @@ int main(int argc, char** argv) {
         }
     }
     char err[1024] = {0};
+    if (!devices.empty()) {
+        if (rt_host_compute_image_devices(ssaa.c_str(), (uint32_t)depth, scene.c_str(), output.c_str(), have_base ? base_dir.c_str() : nullptr,
+                                          devices.data(), (uint32_t)devices.size(), split_tiles ? 1 : 0, seed, err, sizeof(err))) {
+            fprintf(stderr, "error: %s\n", err);
+            return 101;
+        }
+        return 0;
+    }
     if (rt_host_compute_image(ssaa.c_str(), (uint32_t)depth, scene.c_str(), output.c_str(), have_base ? base_dir.c_str() : nullptr, device, seed, err, sizeof(err))) {
         fprintf(stderr, "error: %s\n", err);
         return 101;   // a Rust panic exits with 101

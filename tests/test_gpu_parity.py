@@ -339,6 +339,23 @@ def test_device_pointer_api_matches_host_api(ctx):
     assert np.abs(rgb.cpu().numpy().astype(int) - rgb_h.astype(int)).max() <= 1
 
 
+def test_compute_image_on_several_contexts(ctx, tmp_path):
+    """--devices / --split (SURVEY 8b additive flags): two contexts (here on the same GPU) share the
+    frame; tile split reproduces the single-device image exactly, sample split up to the order of the
+    float sums."""
+    scene = os.path.join(GOLDEN, "scenes", "spheres", "spheres.yaml")
+    one, tiles, spp = str(tmp_path / "one.png"), str(tmp_path / "tiles.png"), str(tmp_path / "spp.png")
+    rt.compute_image("jitter:3", 5, scene, one, base_dir=GOLDEN, seed=21)
+    rt.compute_image("jitter:3", 5, scene, tiles, base_dir=GOLDEN, seed=21, devices=[0, 0, 0], split="tiles")
+    rt.compute_image("jitter:3", 5, scene, spp, base_dir=GOLDEN, seed=21, devices=[0, 0], split="spp")
+    a, b, c = rt.read_png(one).astype(int), rt.read_png(tiles).astype(int), rt.read_png(spp).astype(int)
+    assert a.shape == (500, 500, 3)
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3     # shadow-ray float atomics: last bits only
+    assert np.abs(a - c).max() <= 1 and (a != c).mean() < 1e-3
+    with pytest.raises(Exception):
+        rt.compute_image("jitter:3", 5, scene, one, base_dir=GOLDEN, devices=[99])
+
+
 # ------------------------------------------------------------------ GPU BVH builder (SURVEY 8f-3)
 def _boxes_of_triangles(verts, tris):
     v = np.asarray(verts, np.float32)[np.asarray(tris)]
