@@ -221,3 +221,24 @@ def test_bvh_of_the_million_triangle_torus():
     boxes = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
     nodes, depth, stack = _bvh_validate(boxes)
     assert depth <= 16 and stack <= 48 and nodes < 1000000
+
+
+def test_cli_argument_errors_follow_clap():
+    """main.rs:8-19: missing / malformed arguments are usage errors (exit 2) before anything touches a GPU."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer-rust_amd", "rtamd-render")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    run = lambda *a: subprocess.run([exe, *a], capture_output=True, text=True, timeout=60)
+    r = run()
+    assert r.returncode == 2 and "--scene-path <SCENE_PATH>" in r.stderr and "--output-path <OUTPUT_PATH>" in r.stderr
+    r = run("-s", "x.yaml", "-o", "y.png", "--depth", "300")
+    assert r.returncode == 2 and "not a u8" in r.stderr
+    r = run("-s", "x.yaml", "-o", "y.png", "--ssaa", "bogus:2")
+    assert r.returncode == 2 and "error parsing ssaa argument: unknown method" in r.stderr
+    r = run("-s", "x.yaml", "-o", "y.png", "--devices", "0,a")
+    assert r.returncode == 2 and "--devices" in r.stderr
+    r = run("-s", "x.yaml", "-o", "y.png", "--split", "rows")
+    assert r.returncode == 2 and "spp or tiles" in r.stderr
+    r = run("--help")
+    assert r.returncode == 0 and "--devices" in r.stdout and "--ssaa <SSAA>" in r.stdout
