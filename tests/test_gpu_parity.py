@@ -326,6 +326,34 @@ def test_full_size_c5_hits_and_properties(ctx):
     assert np.allclose(full + b, two, rtol=1e-5, atol=1e-6)
 
 
+def test_full_size_c3_and_c4_hit_windows(ctx):
+    """The other two BASELINE configurations at their full sizes: C3 (RTIOW spheres, 1920x1080) and C4
+    (1,000,000-triangle torus + plane, 3840x2160): windows of the frame against the brute-force oracle."""
+    sc = scenegen.scene_c3()
+    assert (sc["width"], sc["height"]) == (1920, 1080)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    got = ctx.primary_hits(0.0, 0.0)
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    for crop in ((860, 1060, 500, 600), (0, 160, 980, 1080), (1700, 1920, 0, 60)):      # x0, x1, row0, row1
+        want = osc.primary_hits(0.0, 0.0, crop=crop)
+        sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
+        check_hits(sub_, want, allow_id_mismatch=4, curved=True)
+    sc = scenegen.scene_c4()
+    assert (sc["width"], sc["height"]) == (3840, 2160)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    got = ctx.primary_hits(0.0, 0.0)
+    on_mesh = got["triangle_id"] >= 0
+    assert on_mesh.sum() > 500000 and (got["object_id"] >= 0).mean() > 0.6        # torus and plane fill the frame
+    rows, cols = np.nonzero(on_mesh)
+    r0, c0 = int(np.median(rows)), int(np.median(cols))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    for crop in ((c0 - 10, c0 + 10, r0 - 6, r0 + 6), (int(cols.min()) - 4, int(cols.min()) + 12, int(rows[cols.argmin()]) - 4, int(rows[cols.argmin()]) + 4)):
+        crop = (max(crop[0], 0), min(crop[1], 3840), max(crop[2], 0), min(crop[3], 2160))
+        want = osc.primary_hits(0.0, 0.0, crop=crop)
+        sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
+        check_hits(sub_, want, allow_id_mismatch=2)
+
+
 def test_device_pointer_api_matches_host_api(ctx):
     import torch
     load_pair("spheres", ctx)
