@@ -107,8 +107,10 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
         radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
         // slot == path id: no compaction (one atomic per wave on a single counter costs more than the
         // whole kernel).  Padding slots of border tiles are flagged and skipped downstream.
-        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = make_float4(0.f, 0.f, __uint_as_float(SRC_INVALID), __uint_as_float(pid));
-        float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
+        // A primary ray is 16 bytes, (d.x, d.y, d.z, bits(rng)): its origin is the eye, its throughput 1,
+        // its path id the slot and it starts on nothing; iteration 0 of k_closest_hit and k_shade fill
+        // that in.  d == 0 marks a padding slot.  (48-byte primaries cost 2 ms more per 133 M paths.)
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
             const uint32_t s = pp.s_begin + s_local;
             const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
@@ -127,13 +129,9 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
             const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
             const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
             const f3 d = mk((float)(ddx * inv), (float)(ddy * inv), (float)(ddz * inv));
-            A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], d.x);
-            B = make_float4(d.y, d.z, __uint_as_float(SRC_NONE), __uint_as_float(pid));
-            C = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+            A = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
         }
         q.a[pid] = A;
-        q.b[pid] = B;
-        q.c[pid] = C;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
 }
@@ -356,7 +354,13 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         // A refill is a chain of dependent memory round trips during which the wave's other
                         // lanes wait, so it is kept to two: (ray words a and b) -> (record of the primitive
                         // the ray starts on).  Planes and big spheres come from LDS.
-                        const float4 B = q.b[ray], A = q.a[ray];
+                        float4 A = q.a[ray], B;
+                        if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
+                            B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
+                            A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], A.x);
+                        } else {
+                            B = q.b[ray];
+                        }
                         src = __float_as_uint(B.z);
                         if (src == SRC_INVALID) {
                             hits[ray] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);   // padding slot
@@ -670,11 +674,20 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS;
         if (i < n) {
-            const float4 A = qi.a[i], B = qi.b[i], C = qi.c[i], H = hits[i];
-            const f3 o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
-            pid = __float_as_uint(B.w);
-            thr = mk(C.x, C.y, C.z);
-            rng = __float_as_uint(C.w);
+            const float4 A = qi.a[i], H = hits[i];
+            f3 o, d;
+            if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
+                o = mk(sc.eye[0], sc.eye[1], sc.eye[2]); d = mk(A.x, A.y, A.z);
+                pid = i;
+                thr = mk(1.f, 1.f, 1.f);
+                rng = __float_as_uint(A.w);
+            } else {
+                const float4 B = qi.b[i], C = qi.c[i];
+                o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
+                pid = __float_as_uint(B.w);
+                thr = mk(C.x, C.y, C.z);
+                rng = __float_as_uint(C.w);
+            }
             code = __float_as_uint(H.y);
             if (code == HIT_INVALID) {
                 // padding slot: not a ray
@@ -843,10 +856,11 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     const uint32_t n = min(ctl[CTL_QCOUNT + 0], capacity);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 A = q.a[i], B = q.b[i], H = hits[i];
-    const uint32_t pid = __float_as_uint(B.w);
+    const float4 D = q.a[i], H = hits[i];      // iteration 0: (d, rng), slot == path id
+    const float4 A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], D.x), B = make_float4(D.y, D.z, 0.f, 0.f);
+    const uint32_t pid = i;
     uint32_t x, row;
-    if (__float_as_uint(B.z) == SRC_INVALID || !slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
+    if (__float_as_uint(H.y) == HIT_INVALID || !slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
     const size_t px = (size_t)row * sc.width + x;
     const uint32_t code = __float_as_uint(H.y);
     int32_t o = -1, t = -1;
