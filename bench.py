@@ -151,9 +151,9 @@ def main():
     if rank == 0:
         n_planes = len([o for o in sc["objects"] if o["type"] == "Plane"])
         # algorithmic bytes of one closest-hit query ("k_closest_hit"): 32 B ray words a,b in (16 B for a primary ray),
-        # 16 B hit record out, 64 B per BVH node visited, 48 B per primitive tested, 32 B per plane
+        # 8 B hit record out, 64 B per BVH node visited, 48 B per primitive tested, 32 B per plane
         r0 = float(st["rays_per_iteration"][0]) / max(1.0, float(st["rays_total"]))     # primary rays are 16 B, the others 32 B (a, b)
-        bytes_per_ray = (16.0 * r0 + 32.0 * (1.0 - r0)) + 16.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray + 32.0 * n_planes
+        bytes_per_ray = (16.0 * r0 + 32.0 * (1.0 - r0)) + 8.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray + 32.0 * n_planes
         flops_per_ray = 40.0 * nodes_per_ray + 45.0 * prims_per_ray + 10.0 * n_planes
         launches = max(1, st["hit_launches"])
         rays_per_launch = st["rays_total"] / launches

@@ -43,7 +43,7 @@ struct rt_context {
     uint32_t capacity = 0;      // rays per queue
     uint32_t path_capacity = 0; // radiance slots
     RayQueue q[2]{};
-    float4* hits = nullptr;
+    float2* hits = nullptr;    // (t, code) per ray
     float4* radiance = nullptr;
     uint32_t* ctl = nullptr;
     unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 3 words
@@ -130,7 +130,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].b, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].c, (size_t)capacity * sizeof(float4)));
         }
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float4)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
         ctx->capacity = capacity;
         ctx->path_capacity = paths;

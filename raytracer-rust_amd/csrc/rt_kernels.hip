@@ -142,14 +142,13 @@ struct Best {
     float t;
     uint32_t code;   // HIT_MISS, prim index (leaf order) or HIT_PLANE_BIT | plane
     uint32_t gid;    // tie-break key
-    float a, b;      // barycentrics (triangles)
 };
 
 // scene.rs:43 / intersections.rs:170: strict '>' while scanning in object/triangle order
 // == smallest t, then smallest scan rank.
-__device__ __forceinline__ void consider(Best& best, float t, uint32_t code, uint32_t gid, float a, float b) {
+__device__ __forceinline__ void consider(Best& best, float t, uint32_t code, uint32_t gid) {
     if (t < best.t || (t == best.t && gid < best.gid)) {
-        best.t = t; best.code = code; best.gid = gid; best.a = a; best.b = b;
+        best.t = t; best.code = code; best.gid = gid;
     }
 }
 
@@ -235,6 +234,14 @@ __device__ __forceinline__ bool tri_hit_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac, floa
     // NaN (M == 0) is rejected here; the reference would accept it when no hit exists yet
     return a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f;
 }
+// a = Ma / M, b = Mb / M only (intersections.rs:155-160)
+__device__ __forceinline__ void tri_ab_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac, float& a, float& b) {
+#pragma clang fp contract(off)
+    const f3 res = sub_ref(o, A);
+    const float m = det3_ref(d, ab, ac);
+    a = det3_ref(d, res, ac) / m;
+    b = det3_ref(d, ab, res) / m;
+}
 // raytrace.rs:40-42: origin + direction * t, two roundings
 __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
 #pragma clang fp contract(off)
@@ -267,7 +274,7 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 #endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float4* __restrict__ hits, uint32_t* __restrict__ ctl,
+__global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float2* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     float idx = 0.f, idy = 0.f, idz = 0.f;
     Best best;
-    best.t = 0.f; best.code = HIT_MISS; best.gid = 0u; best.a = 0.f; best.b = 0.f;
+    best.t = 0.f; best.code = HIT_MISS; best.gid = 0u;
 
     for (;;) {
         // ---------------- refill: idle lanes take the next rays of the wave's range
@@ -363,10 +370,10 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         }
                         src = __float_as_uint(B.z);
                         if (src == SRC_INVALID) {
-                            hits[ray] = make_float4(-1.f, __uint_as_float(HIT_INVALID), 0.f, 0.f);   // padding slot
+                            hits[ray] = make_float2(-1.f, __uint_as_float(HIT_INVALID));   // padding slot
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
-                            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu; best.a = 0.f; best.b = 0.f;
+                            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu;
                             // a ray that starts on a triangle tests that triangle with the reference's own
                             // operation sequence (see tri_hit_ref); the traversal below skips it
                             if (src < sc.n_leaf_prims) {
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                     float t, a, b;
                                     if (COUNT) cnt_prims++;
                                     if (tri_hit_ref(o, d, mk(s0.x, s0.y, s0.z), mk(s0.w, s1.x, s1.y), mk(s1.z, s1.w, s2.x), t, a, b))
-                                        consider(best, t, src, __float_as_uint(s2.y), a, b);
+                                        consider(best, t, src, __float_as_uint(s2.y));
                                 }
                             }
                             // (the pointer is laundered so that the reads stay here: hoisted out of the loop
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 if (src == (HIT_PLANE_BIT | p)) continue;   // t would be ~0 < 1e-5 in the reference's f64
                                 const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
                                 if (!(t >= 1e-5f)) continue;
-                                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w), 0.f, 0.f);
+                                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w));
                             }
                             // big spheres (kept out of the BVH), full f64
                             for (uint32_t pi = sc.n_leaf_prims; pi < sc.n_prims; ++pi) {
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 else { r0 = prims[3 * pi]; r1 = prims[3 * pi + 1]; r2 = prims[3 * pi + 2]; }
                                 if (COUNT) cnt_prims++;
                                 const float t = sphere_hit64(r0, r1, o, d, src == pi);
-                                if (t > 0.f) consider(best, t, pi, __float_as_uint(r2.y), 0.f, 0.f);
+                                if (t > 0.f) consider(best, t, pi, __float_as_uint(r2.y));
                             }
                             if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 pcur = pend = 0;
                                 active = true;
                             } else {
-                                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+                                hits[ray] = make_float2(best.t, __uint_as_float(best.code));
                             }
                         }
                     }
@@ -546,12 +553,12 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         const float ua = dot(tv, pv) * sg, ub = dot(d, qv) * sg, ut = dot(e2, qv) * sg, ad = fabsf(det);
                         if (ad > 0.f && ua >= 0.f && ub >= 0.f && ua + ub <= ad && ut >= 0.f) {
                             const float inv = 1.0f / ad;
-                            consider(best, ut * inv, pi, gid, ua * inv, ub * inv);
+                            consider(best, ut * inv, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
                         }
                     }
                 } else {
                     const float t = sphere_hit(L0, L1, o, d, src == pi);
-                    if (t > 0.f) consider(best, t, pi, gid, 0.f, 0.f);
+                    if (t > 0.f) consider(best, t, pi, gid);
                 }
                 pcur++;
                 if (pcur == pend && node < 0) {
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 }
             }
             if (active && node == STACK_SENTINEL && pcur >= pend) {
-                hits[ray] = make_float4(best.t, __uint_as_float(best.code), best.a, best.b);
+                hits[ray] = make_float2(best.t, __uint_as_float(best.code));
                 active = false;
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
@@ -661,7 +668,7 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
 // (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.
-__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue qi, const float4* __restrict__ hits, RayQueue qo,
+__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
@@ -674,7 +681,8 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS;
         if (i < n) {
-            const float4 A = qi.a[i], H = hits[i];
+            const float4 A = qi.a[i];
+            const float2 H = hits[i];
             f3 o, d;
             if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                 o = mk(sc.eye[0], sc.eye[1], sc.eye[2]); d = mk(A.x, A.y, A.z);
@@ -715,7 +723,9 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
                         p = at_ref(o, d, t);                                               // intersections.rs:172
                         if (__float_as_uint(S.w) & SMETA_HAS_UV) {                         // intersections.rs:177-183
                             const float* uv = sc.uvs + 6 * (size_t)sc.meta[code].w;
-                            const float a = H.z, b = H.w, c = 1.f - a - b;
+                            float a, b;
+                            tri_ab_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2, a, b);          // intersections.rs:159-160
+                            const float c = 1.f - a - b;
                             u = a * uv[2] + b * uv[4] + c * uv[0];
                             v = a * uv[3] + b * uv[5] + c * uv[1];
                         }
@@ -850,13 +860,14 @@ __global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum
 }
 
 // per-pixel hit record for rt_primary_hits
-__global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, RayQueue q, const float4* __restrict__ hits,
+__global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, RayQueue q, const float2* __restrict__ hits,
                                                   const uint32_t* __restrict__ ctl, uint32_t capacity, int32_t* __restrict__ obj,
                                                   int32_t* __restrict__ tri, float* __restrict__ tout, float* __restrict__ nout) {
     const uint32_t n = min(ctl[CTL_QCOUNT + 0], capacity);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 D = q.a[i], H = hits[i];      // iteration 0: (d, rng), slot == path id
+    const float4 D = q.a[i];                   // iteration 0: (d, rng), slot == path id
+    const float2 H = hits[i];
     const float4 A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], D.x), B = make_float4(D.y, D.z, 0.f, 0.f);
     const uint32_t pid = i;
     uint32_t x, row;
@@ -931,7 +942,7 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
     uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
 }
-void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float4* hits, uint32_t* ctl, int it, uint32_t capacity,
+void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
                         uint32_t max_rays, bool counters, hipStream_t st) {
     uint32_t per_cu = HIT_BLOCKS_PER_CU;
     if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
@@ -940,7 +951,7 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
     if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
     else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
 }
-void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float4* hits, RayQueue qo, float4* radiance,
+void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 2u, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
@@ -951,7 +962,7 @@ void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* r
 void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(n_values, 256)), dim3(256), 0, st, accum, n_values, inv_spp, rgb8, color);
 }
-void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float4* hits, const uint32_t* ctl, uint32_t capacity,
+void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float2* hits, const uint32_t* ctl, uint32_t capacity,
                      int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st) {
     hipLaunchKernelGGL(k_hit_info, dim3(cdiv(pp.n_paths, 256)), dim3(256), 0, st, sc, pp, q, hits, ctl, capacity, obj, tri, t, nrm);
 }
