@@ -476,8 +476,8 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 // axes (their maximum) is just as safe but useless: an axis the ray is almost parallel to
                 // has a huge |idir|, and its bound would then loosen the other two slabs so far that such
                 // a ray walks most of the tree (those few rays were the multi-ms tail of a launch).
-                const float wx = fmaf(256.f, sx, fabsf(pox)) * fabsf(idx), wy = fmaf(256.f, sy, fabsf(poy)) * fabsf(idy),
-                            wz = fmaf(256.f, sz, fabsf(poz)) * fabsf(idz);
+                // ((|p-o| + 256 s) |idir| from the products that exist anyway: |b| + 256 |s idir|)
+                const float wx = fmaf(256.f, fabsf(sxi), fabsf(bxi)), wy = fmaf(256.f, fabsf(syi), fabsf(byi)), wz = fmaf(256.f, fabsf(szi), fabsf(bzi));
                 const float bnx = fmaf(wx, -0x1p-21f, bxi), bny = fmaf(wy, -0x1p-21f, byi), bnz = fmaf(wz, -0x1p-21f, bzi);
                 const float bfx = fmaf(wx, 0x1p-21f, bxi), bfy = fmaf(wy, 0x1p-21f, byi), bfz = fmaf(wz, 0x1p-21f, bzi);
                 // entry / exit planes by the sign of the ray direction
