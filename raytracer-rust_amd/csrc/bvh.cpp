@@ -156,6 +156,7 @@ void encode_node(GpuNode& g, const Box& node_box, const Box* child_boxes, const 
         scale[k] = std::ldexp(1.0, e);
     }
     g.exps = e8[0] | (e8[1] << 8) | (e8[2] << 16);
+    g.scale_y = (float)scale[1]; g.scale_z = (float)scale[2];
     uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         g.child[i] = i < n_children ? child_codes[i] : CHILD_EMPTY;
@@ -360,6 +361,11 @@ void validate_bvh(const Bvh& bvh, const std::vector<PrimBox>& pb) {
         for (int k = 0; k < 3; ++k) { e.mn[k] = INFINITY; e.mx[k] = -INFINITY; }
         const uint32_t ex[3] = {g.exps & 0xFFu, (g.exps >> 8) & 0xFFu, (g.exps >> 16) & 0xFFu};
         const uint32_t qlo[3] = {g.qlo[0], g.qlo[1], g.qlo[2]}, qhi[3] = {g.qhi_x, g.qhi_y, g.qhi_z};
+        {
+            uint32_t by = ex[1] << 23, bz = ex[2] << 23, gy, gz;
+            memcpy(&gy, &g.scale_y, 4); memcpy(&gz, &g.scale_z, 4);
+            if (gy != by || gz != bz) raise("node %d: float scales differ from the exponent bytes", x);
+        }
         for (int c = 0; c < 4; ++c) {
             if (g.child[c] == CHILD_EMPTY) continue;
             Ext sub;

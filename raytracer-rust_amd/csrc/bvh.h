@@ -21,7 +21,8 @@ struct PrimBox {
 //                                  ~child = (first << 3) | (count - 1), `first` indexes the
 //                                  leaf-ordered primitive array.
 //   w2 = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   one byte per child, child i in bits 8i..8i+7
-//   w3 = (qhi.y[4], qhi.z[4], 0, 0)
+//   w3 = (qhi.y[4], qhi.z[4], scale_y, scale_z)   the y and z scales again, as floats (the kernel reads
+//                                  them from here and takes scale_x from exps with one shift)
 // child box = [p + qlo * scale, p + qhi * scale] (qlo rounded down, qhi rounded up: conservative).
 // The kernel bounds its own rounding error per node, so no further padding is needed.
 constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
@@ -31,7 +32,8 @@ struct GpuNode {
     uint32_t exps;
     int32_t child[4];
     uint32_t qlo[3], qhi_x;
-    uint32_t qhi_y, qhi_z, pad0, pad1;
+    uint32_t qhi_y, qhi_z;
+    float scale_y, scale_z;
 };
 static_assert(sizeof(GpuNode) == 64, "node must be 64 bytes");
 

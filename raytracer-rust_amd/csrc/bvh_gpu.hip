@@ -221,7 +221,7 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const uint32_t* __restric
     }
     g.qlo[0] = qlo[0]; g.qlo[1] = qlo[1]; g.qlo[2] = qlo[2];
     g.qhi_x = qhi[0]; g.qhi_y = qhi[1]; g.qhi_z = qhi[2];
-    g.pad0 = 0; g.pad1 = 0;
+    g.scale_y = (float)scale[1]; g.scale_z = (float)scale[2];
     nodes[it.wide] = g;
 }
 

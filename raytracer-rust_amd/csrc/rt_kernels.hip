@@ -464,8 +464,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 // 4-wide node, 8-bit child boxes relative to (p, 2^e) -- bvh.h
                 if (COUNT) cnt_nodes++;
                 const uint32_t ex = __float_as_uint(L0.w);
-                const float sx = __uint_as_float((ex & 0xFFu) << 23), sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23),
-                            sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
+                // scale_x: the shift moves the low bit of the next exponent byte into the sign, |.| drops it
+                // (a free source modifier); scale_y and scale_z are stored as floats
+                const float sx = fabsf(__uint_as_float(ex << 23)), sy = L3.z, sz = L3.w;
                 const float pox = L0.x - o.x, poy = L0.y - o.y, poz = L0.z - o.z;
                 // plane distance t = q * (s * idir) + (p - o) * idir: s is a power of two, so s * idir and
                 // q * (s * idir) are exact and one FMA per plane carries two roundings in all
