@@ -292,7 +292,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
     // ---- records: BVH primitives in leaf order, then the big spheres
     std::vector<float4> prims((size_t)n_prims * 3);
     std::vector<int4> meta(n_prims);
-    std::vector<float4> smeta(n_prims);
+    std::vector<float4> smeta((size_t)n_prims * 4);   // 64-byte shading records: (normal, material | flags) + a copy of the primitive record
     std::vector<float> uvs;
     for (uint32_t k = 0; k < n_prims; ++k) {
         uint32_t src = k < n_leaf_prims ? bvh_src[bvh.order[k]] : big_src[k - n_leaf_prims];
@@ -303,9 +303,9 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
             uint32_t w[4] = {0u, gid_sphere[src], PRIM_SPHERE, 0u};
             std::memcpy(&r[2], w, 16);
             meta[k] = make_int4(d->sphere_object[src], -1, d->sphere_material[src], -1);
-            uint32_t mw = (uint32_t)d->sphere_material[src];
+            uint32_t mw = (uint32_t)d->sphere_material[src] | SMETA_SPHERE;
             float mf; std::memcpy(&mf, &mw, 4);
-            smeta[k] = make_float4(0.f, 0.f, 0.f, mf);
+            smeta[(size_t)k * 4] = make_float4(0.f, 0.f, 0.f, mf);
         } else {
             uint64_t t = src - d->n_spheres;
             const float* v = &tri_f32[9 * t];
@@ -332,8 +332,9 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
             if (nl > 0.0) { nn[0] /= nl; nn[1] /= nl; nn[2] /= nl; }
             uint32_t mw = (uint32_t)d->tri_material[t] | (has_uv ? SMETA_HAS_UV : 0u);
             float mf; std::memcpy(&mf, &mw, 4);
-            smeta[k] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], mf);
+            smeta[(size_t)k * 4] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], mf);
         }
+        for (int q = 0; q < 3; ++q) smeta[(size_t)k * 4 + 1 + q] = r[q];
     }
     std::vector<float4> nodes(bvh.nodes.size() * 4);
     if (!bvh.nodes.empty()) std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(GpuNode));

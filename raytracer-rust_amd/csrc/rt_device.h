@@ -13,6 +13,8 @@ constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: 
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
 constexpr uint32_t SMETA_HAS_UV = 0x80000000u;
+constexpr uint32_t SMETA_SPHERE = 0x40000000u;
+constexpr uint32_t SMETA_FLAGS = SMETA_HAS_UV | SMETA_SPHERE;
 constexpr int32_t CHILD_EMPTY_CODE = (int32_t)0x80000000;   // == bvh.h CHILD_EMPTY
 constexpr uint32_t LDS_STACK = 16;            // traversal-stack entries per lane kept in LDS (4 KB per wave)
 constexpr uint32_t HIT_BLOCKS_PER_CU = 8;     // persistent closest-hit blocks (256 threads) per CU
@@ -51,7 +53,8 @@ struct RayQueue {
 // index): the tie-break key of scene.rs:43 / intersections.rs:170.
 //
 // meta (int4 per primitive, leaf order): (object index, triangle index or -1, material, uv offset or -1)
-// smeta (float4 per primitive, leaf order), what shading needs: (n.x, n.y, n.z, bits(material | SMETA_HAS_UV)).
+// smeta (4 x float4 = one 64-byte line per primitive, leaf order), what shading gathers:
+//   [0] = (n.x, n.y, n.z, bits(material | SMETA_HAS_UV | SMETA_SPHERE)), [1..3] = copy of the primitive record.
 //   n = the triangle's unit normal, normalized((B-A) x (C-A)) (intersections.rs:169) evaluated in f64 on
 //   the host and rounded once.  The device's edges come from f32 vertices: on a 1M-triangle mesh (edges of
 //   0.01 at coordinates of 6) their cross product is off by 1.5e-5, above the 1e-5 bar.  Spheres: n unused.

@@ -647,7 +647,16 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 
 // Block-level compaction: every thread of the block must call this (converged).  Threads with
 // `want` get `per_lane` consecutive slots; ONE atomic per 1024-thread block.
-constexpr int SHADE_THREADS = 1024;
+#ifndef RT_SHADE_THREADS
+#define RT_SHADE_THREADS 1024
+#endif
+#ifndef RT_SHADE_MINWAVES
+#define RT_SHADE_MINWAVES 8   // <= 64 VGPRs: two 1024-thread blocks per CU, one computes while the other waits at its barriers
+#endif
+#ifndef RT_SHADE_GRID_MUL
+#define RT_SHADE_GRID_MUL 2u
+#endif
+constexpr int SHADE_THREADS = RT_SHADE_THREADS;
 __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, uint32_t* counter, uint32_t* lds /* [17] */) {
     const uint64_t m = __ballot(want);
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -669,7 +678,7 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
 // (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.
-__global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
+__global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
@@ -713,16 +722,18 @@ __global__ __launch_bounds__(SHADE_THREADS) void k_shade(DevScene sc, RayQueue q
                     mat = __float_as_int(P1.w);
                     p = at_ref(o, d, t);                                                   // raytrace.rs:40-42
                 } else {
-                    const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
-                    const float4 S = sc.smeta[code];
-                    mat = (int)(__float_as_uint(S.w) & ~SMETA_HAS_UV);
-                    if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                    // one 64-byte shading record per primitive: a single cache line per gather
+                    const float4* __restrict__ rec = sc.smeta + 4 * (size_t)code;
+                    const float4 S = rec[0], r0 = rec[1], r1 = rec[2], r2 = rec[3];
+                    const uint32_t sw = __float_as_uint(S.w);
+                    mat = (int)(sw & ~SMETA_FLAGS);
+                    if (!(sw & SMETA_SPHERE)) {
                         const f3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
                         // hit point from the reference's own t sequence (see tri_hit_ref)
                         t = tri_t_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2);
                         p = at_ref(o, d, t);                                               // intersections.rs:172
-                        if (__float_as_uint(S.w) & SMETA_HAS_UV) {                         // intersections.rs:177-183
+                        if (sw & SMETA_HAS_UV) {                                           // intersections.rs:177-183
                             const float* uv = sc.uvs + 6 * (size_t)sc.meta[code].w;
                             float a, b;
                             tri_ab_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2, a, b);          // intersections.rs:159-160
@@ -890,7 +901,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
             const int4 M = sc.meta[code];
             o = M.x; t = M.y;
             if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                const float4 S = sc.smeta[code];
+                const float4 S = sc.smeta[4 * (size_t)code];
                 nrm = mk(S.x, S.y, S.z);
             } else {
                 const f3 org = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
@@ -954,7 +965,7 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
-    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 2u, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
+    uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
