@@ -173,16 +173,30 @@ __device__ __forceinline__ SphereQ sphere_quadratic(const float4 r0, const float
     q.disc = q.hb * q.hb - q.a * (ocx * ocx + ocy * ocy + ocz * ocz - rad * rad);
     return q;
 }
-// Full f64 roots: big spheres (tested once per ray, all lanes together).
+// f64 roots for the big spheres (tested once per ray at refill, all lanes together).  The square root and
+// the reciprocal come from the f32 hardware estimates and one Newton step in f64 each (relative error
+// ~1e-14, far below the f32 result's half ulp even after the cancellation in -hb -+ sq); the library's
+// f64 sqrt and two f64 divisions were ~150 half-rate instructions per refill.
+__device__ __forceinline__ double rcp_newton(double a) {
+    const double r = (double)__builtin_amdgcn_rcpf((float)a);
+    return r * (2.0 - a * r);
+}
 __device__ __forceinline__ float sphere_hit64(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
     const SphereQ q = sphere_quadratic(r0, r1, o, d);
+    const double ia = rcp_newton(q.a);     // a = d.d ~ 1
     if (from_self) {
-        const double t = -2.0 * q.hb / q.a;
+        const double t = -2.0 * q.hb * ia;
         return t > 1e-5 ? (float)t : -1.f;
     }
     if (!(q.disc >= 0.0)) return -1.f;
-    const double sq = sqrt(q.disc);
-    const double t1 = (-q.hb - sq) / q.a, t2 = (-q.hb + sq) / q.a;
+    double sq;
+    if (q.disc > 1e-30 && q.disc < 1e30) {
+        const double y = (double)__builtin_amdgcn_rsqf((float)q.disc);
+        sq = q.disc * (y * (1.5 - 0.5 * q.disc * y * y));
+    } else {
+        sq = sqrt(q.disc);
+    }
+    const double t1 = (-q.hb - sq) * ia, t2 = (-q.hb + sq) * ia;
     if (t1 > 1e-5) return (float)t1;
     if (t2 > 1e-5) return (float)t2;
     return -1.f;
@@ -417,9 +431,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             }
                             if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
-                                idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
-                                idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
-                                idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+                                // (v_rcp_f32, 1 ulp: the node test's rounding bound has room for it, see there;
+                                // three IEEE divisions were 30 instructions per refill)
+                                idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+                                idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+                                idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
                                 stk[0] = (uint32_t)STACK_SENTINEL;
                                 sp = 1;
                                 node = 0;            // root is always an inner node
