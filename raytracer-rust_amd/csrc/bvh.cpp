@@ -1,6 +1,7 @@
 #include "bvh.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -261,21 +262,73 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
         }
     }
 
-    // collapse the binary tree to 4-wide nodes and flatten depth-first.  A wide node adopts the
-    // children of its binary child with the largest surface area until it has four children.
+    // collapse the binary tree to 4-wide nodes and flatten depth-first.  Which binary nodes survive as
+    // wide nodes is chosen by dynamic programming on the SAH cost (Ylitie et al. 2017, for 4 slots):
+    // cost[x][k-1] = cheapest way to hand the subtree of x to its parent as at most k children, where a
+    // child is a leaf (area * primitives * c_prim) or a wide node (area * c_node + its own four slots
+    // split between its two binary children).  Children are created after their parents in tmp, so a
+    // reverse sweep is a post-order.  (Leaves are fixed, so this minimises the summed area of the wide
+    // nodes.  Against the greedy rule "adopt the children of the child with the largest area": 20 %
+    // fewer nodes, 1.5-5 % fewer node visits per ray, C4 +2.5 %, C5 +0.6 % rays/s.)
     auto leaf_code = [&](const TmpNode& t) { return ~(int32_t)((t.first << 3) | (t.count - 1)); };
+    const float c_node = 2.0f, c_prim = 1.0f;   // a node step costs about two primitive steps
+    std::vector<std::array<float, 4>> cost(tmp.size());
+    std::vector<std::array<uint8_t, 4>> part(tmp.size());   // [k-1]: 0 = x stays ONE child, i = left subtree gets i of the k slots
+    std::vector<uint8_t> part_node(tmp.size(), 0);           // x as a wide node: its left subtree gets i of the 4 slots
+    const bool greedy = getenv("RTAMD_COLLAPSE_GREEDY") != nullptr;   // tuning experiments only
+    if (!greedy) {
+        for (size_t xi = tmp.size(); xi-- > 0;) {
+            const TmpNode& t = tmp[xi];
+            const float area = t.box.half_area();
+            if (t.left < 0) {
+                for (int k = 0; k < 4; ++k) { cost[xi][k] = area * (float)t.count * c_prim; part[xi][k] = 0; }
+                continue;
+            }
+            const auto &cl = cost[(size_t)t.left], &cr = cost[(size_t)t.right];
+            float as_node = INFINITY;
+            for (int i = 1; i <= 3; ++i) {
+                const float c = cl[i - 1] + cr[4 - i - 1];
+                if (c < as_node) { as_node = c; part_node[xi] = (uint8_t)i; }
+            }
+            as_node += area * c_node;
+            cost[xi][0] = as_node; part[xi][0] = 0;
+            for (int k = 2; k <= 4; ++k) {
+                float best = as_node; uint8_t choice = 0;
+                for (int i = 1; i < k; ++i) {
+                    const float c = cl[i - 1] + cr[k - i - 1];
+                    if (c < best) { best = c; choice = (uint8_t)i; }
+                }
+                cost[xi][k - 1] = best; part[xi][k - 1] = choice;
+            }
+        }
+    }
     struct Wide { int32_t tmp; int32_t kids[4]; int n; };
     auto gather = [&](int32_t x) {
         Wide w; w.tmp = x; w.n = 0;
         if (tmp[x].left < 0) { w.kids[w.n++] = x; return w; }      // a lone leaf: one child
-        w.kids[w.n++] = tmp[x].left; w.kids[w.n++] = tmp[x].right;
-        while (w.n < 4) {
-            int best = -1; float area = -1.f;
-            for (int i = 0; i < w.n; ++i)
-                if (tmp[w.kids[i]].left >= 0 && tmp[w.kids[i]].box.half_area() > area) { area = tmp[w.kids[i]].box.half_area(); best = i; }
-            if (best < 0) break;
-            int32_t c = w.kids[best];
-            w.kids[best] = tmp[c].left; w.kids[w.n++] = tmp[c].right;
+        if (greedy) {
+            w.kids[w.n++] = tmp[x].left; w.kids[w.n++] = tmp[x].right;
+            while (w.n < 4) {
+                int best = -1; float area = -1.f;
+                for (int i = 0; i < w.n; ++i)
+                    if (tmp[w.kids[i]].left >= 0 && tmp[w.kids[i]].box.half_area() > area) { area = tmp[w.kids[i]].box.half_area(); best = i; }
+                if (best < 0) break;
+                int32_t c = w.kids[best];
+                w.kids[best] = tmp[c].left; w.kids[w.n++] = tmp[c].right;
+            }
+            return w;
+        }
+        // hand out the four slots as the table says (explicit stack: at most 4 entries)
+        struct Todo { int32_t node; int k; };
+        Todo todo[8]; int nt = 0;
+        todo[nt++] = {tmp[x].right, 4 - (int)part_node[(size_t)x]};
+        todo[nt++] = {tmp[x].left, (int)part_node[(size_t)x]};
+        while (nt > 0) {
+            const Todo td = todo[--nt];
+            const int i = tmp[td.node].left < 0 ? 0 : (int)part[(size_t)td.node][td.k - 1];
+            if (i == 0) { w.kids[w.n++] = td.node; continue; }
+            todo[nt++] = {tmp[td.node].right, td.k - i};
+            todo[nt++] = {tmp[td.node].left, i};
         }
         return w;
     };
