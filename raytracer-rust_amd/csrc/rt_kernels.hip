@@ -284,7 +284,7 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 #define RT_VOTE_WL 1    // (13:9, 1:1, 2:1, 3:1, 9:13 measured)
 #endif
 #ifndef RT_HIT_MIN_WAVES
-#define RT_HIT_MIN_WAVES 6   // min waves per SIMD the register allocator must allow: 80 VGPRs (measured: 5 -> 1.125 ms, 6 -> 1.080, 7 -> 1.138, 8 -> 1.49)
+#define RT_HIT_MIN_WAVES 8   // waves per SIMD the register allocator must allow: 64 VGPRs, no spills (6 waves/80 VGPRs: 4.57 ms per launch, 7: 4.38, 8: 4.30)
 #endif
 
 template <bool COUNT>
@@ -574,7 +574,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         }
                     }
                 } else {
-                    const float t = sphere_hit(L0, L1, o, d, src == pi);
+                    // (o and d are laundered so that their f64 copies are made here: hoisted out of the loop
+                    // they occupy 14 registers for the whole kernel, the difference between 6 and 8 waves/SIMD)
+                    f3 o_ = o, d_ = d;
+                    asm volatile("" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
+                    const float t = sphere_hit(L0, L1, o_, d_, src == pi);
                     if (t > 0.f) consider(best, t, pi, gid);
                 }
                 pcur++;
