@@ -64,6 +64,9 @@ struct Tree {
     uint32_t* last;
     float* box;       // [n-1][6]
     uint32_t* flag;   // [n-1] arrivals
+    float* cost;      // [n-1][4] SAH cost of handing the subtree to its parent as at most k+1 children (bvh.cpp)
+    uint8_t* part;    // [n-1][4] 0 = the node stays ONE child, i = its left subtree gets i of the k+1 slots
+    uint8_t* part_node; // [n-1] the node as a wide node: its left subtree gets i of the 4 slots
 };
 
 __device__ __forceinline__ int delta(const unsigned long long* __restrict__ k, int n, int i, int j) {
@@ -111,6 +114,22 @@ __device__ __forceinline__ void load_box(const Tree& t, const PrimBox* __restric
     }
 }
 
+__device__ __forceinline__ uint32_t kid_size(const Tree& t, int c) { return c < 0 ? 1u : t.last[c] - t.first[c] + 1u; }
+__device__ __forceinline__ float box_half_area(const float b[6]) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// cost of child c of a node for 1..4 slots: a leaf costs area * primitives whatever it is given
+__device__ __forceinline__ void child_cost(const Tree& t, int c, const float b[6], float out[4]) {
+    const uint32_t size = kid_size(t, c);
+    if (c < 0 || size <= MAX_LEAF_PRIMS) {
+        const float v = box_half_area(b) * (float)size;
+        out[0] = out[1] = out[2] = out[3] = v;
+    } else {
+        for (int k = 0; k < 4; ++k) out[k] = t.cost[4 * (size_t)c + k];   // written before c's (fenced) arrival here
+    }
+}
+
 __global__ __launch_bounds__(256) void k_lbvh_boxes(const uint32_t* __restrict__ vals, const PrimBox* __restrict__ boxes, int n, Tree t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -123,9 +142,32 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const uint32_t* __restrict__
         float a[6], b[6];
         load_box(t, boxes, vals, t.left[p], a);
         load_box(t, boxes, vals, t.right[p], b);
+        float cl[4], cr[4], m[6];
+        child_cost(t, t.left[p], a, cl);
+        child_cost(t, t.right[p], b, cr);
         for (int k = 0; k < 3; ++k) {
-            t.box[6 * (size_t)p + k] = fminf(a[k], b[k]);
-            t.box[6 * (size_t)p + 3 + k] = fmaxf(a[3 + k], b[3 + k]);
+            m[k] = fminf(a[k], b[k]);
+            m[3 + k] = fmaxf(a[3 + k], b[3 + k]);
+            t.box[6 * (size_t)p + k] = m[k];
+            t.box[6 * (size_t)p + 3 + k] = m[3 + k];
+        }
+        // the collapse tables of bvh.cpp (dynamic programming on the SAH cost, a node step = two primitive steps)
+        float as_node = INFINITY;
+        uint8_t pn = 1;
+        for (int i = 1; i <= 3; ++i) {
+            const float c = cl[i - 1] + cr[3 - i];
+            if (c < as_node) { as_node = c; pn = (uint8_t)i; }
+        }
+        as_node += 2.0f * box_half_area(m);
+        t.part_node[p] = pn;
+        t.cost[4 * (size_t)p] = as_node; t.part[4 * (size_t)p] = 0;
+        for (int k = 2; k <= 4; ++k) {
+            float best = as_node; uint8_t choice = 0;
+            for (int i = 1; i < k; ++i) {
+                const float c = cl[i - 1] + cr[k - i - 1];
+                if (c < best) { best = c; choice = (uint8_t)i; }
+            }
+            t.cost[4 * (size_t)p + k - 1] = best; t.part[4 * (size_t)p + k - 1] = choice;
         }
         p = t.parent[p];
     }
@@ -133,7 +175,6 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const uint32_t* __restrict__
 
 struct Item { int node; uint32_t wide; };
 
-__device__ __forceinline__ uint32_t kid_size(const Tree& t, int c) { return c < 0 ? 1u : t.last[c] - t.first[c] + 1u; }
 
 // One thread per wide node of the current level.
 __global__ __launch_bounds__(128) void k_lbvh_collapse(const uint32_t* __restrict__ vals, const PrimBox* __restrict__ boxes, Tree t,
@@ -145,25 +186,21 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const uint32_t* __restric
     const Item it = items[i];
     int kids[4];
     float kb[4][6];
-    int nk = 2;
-    kids[0] = t.left[it.node]; kids[1] = t.right[it.node];
-    load_box(t, boxes, vals, kids[0], kb[0]);
-    load_box(t, boxes, vals, kids[1], kb[1]);
-    while (nk < 4) {
-        int best = -1; float area = -1.f;
-        for (int k = 0; k < nk; ++k) {
-            if (kids[k] < 0 || kid_size(t, kids[k]) <= MAX_LEAF_PRIMS) continue;
-            const float dx = kb[k][3] - kb[k][0], dy = kb[k][4] - kb[k][1], dz = kb[k][5] - kb[k][2];
-            const float a = dx * dy + dy * dz + dz * dx;
-            if (a > area) { area = a; best = k; }
+    int nk = 0;
+    {   // hand out the four slots as the tables say (bvh.cpp)
+        int todo_node[8], todo_k[8], nt = 0;
+        const int pn = min(3, max(1, (int)t.part_node[it.node]));
+        todo_node[nt] = t.right[it.node]; todo_k[nt++] = 4 - pn;
+        todo_node[nt] = t.left[it.node]; todo_k[nt++] = pn;
+        while (nt > 0 && nk < 4) {
+            const int c = todo_node[--nt], k = todo_k[nt];
+            const int li = (c < 0 || kid_size(t, c) <= MAX_LEAF_PRIMS) ? 0 : (int)t.part[4 * (size_t)c + k - 1];
+            if (li <= 0 || li >= k || nt > 5) { kids[nk++] = c; continue; }   // one child (leaf or wide node)
+            todo_node[nt] = t.right[c]; todo_k[nt++] = k - li;
+            todo_node[nt] = t.left[c]; todo_k[nt++] = li;
         }
-        if (best < 0) break;
-        const int c = kids[best];
-        kids[best] = t.left[c]; kids[nk] = t.right[c];
-        load_box(t, boxes, vals, kids[best], kb[best]);
-        load_box(t, boxes, vals, kids[nk], kb[nk]);
-        nk++;
     }
+    for (int k = 0; k < nk; ++k) load_box(t, boxes, vals, kids[k], kb[k]);
     // node box and scales (bvh.cpp encode_node)
     float nb[6];
     for (int k = 0; k < 6; ++k) nb[k] = t.box[6 * (size_t)it.node + k];
@@ -271,6 +308,9 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
     GPU_TRY(hipMalloc((void**)&t.last, (size_t)n * 4));
     GPU_TRY(hipMalloc((void**)&t.box, (size_t)n * 24));
     GPU_TRY(hipMalloc((void**)&t.flag, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.cost, (size_t)n * 16));
+    GPU_TRY(hipMalloc((void**)&t.part, (size_t)n * 4));
+    GPU_TRY(hipMalloc((void**)&t.part_node, (size_t)n));
     GPU_TRY(hipMalloc((void**)&d_items[0], (size_t)n * sizeof(Item)));
     GPU_TRY(hipMalloc((void**)&d_items[1], (size_t)n * sizeof(Item)));
     GPU_TRY(hipMalloc((void**)&d_counters, 16));
@@ -320,7 +360,7 @@ int build_bvh_gpu(const std::vector<PrimBox>& boxes, Bvh& out, void* stream, std
 fail:
     (void)hipFree(d_boxes); (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_vals); (void)hipFree(d_vsorted); (void)hipFree(d_temp);
     (void)hipFree(t.left); (void)hipFree(t.right); (void)hipFree(t.parent); (void)hipFree(t.leaf_parent);
-    (void)hipFree(t.first); (void)hipFree(t.last); (void)hipFree(t.box); (void)hipFree(t.flag);
+    (void)hipFree(t.first); (void)hipFree(t.last); (void)hipFree(t.box); (void)hipFree(t.flag); (void)hipFree(t.cost); (void)hipFree(t.part); (void)hipFree(t.part_node);
     (void)hipFree(d_items[0]); (void)hipFree(d_items[1]); (void)hipFree(d_counters); (void)hipFree(d_nodes);
     return err.empty() ? 0 : 1;
 }
