@@ -162,6 +162,7 @@ def main():
         valu = rays_per_launch * flops_per_ray / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
         traffic = None
         valu_busy = None
+        valu_pipe = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc runs)
         if os.path.exists(tpath):
             try:
@@ -169,6 +170,7 @@ def main():
                 if tj.get("workload") == args.workload and not args.small:
                     traffic = tj.get("bytes_per_launch")
                     valu_busy = tj.get("valu_issue_busy")
+                    valu_pipe = tj.get("valu_pipe_busy")
             except Exception:
                 traffic = None
         out = {
@@ -188,12 +190,12 @@ def main():
                          "traffic": traffic, "kernel": "k_closest_hit", "launches": st["hit_launches"], "ms_per_launch": ms_per_launch,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
                          "prims_per_ray": prims_per_ray, "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
-                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS, "valu_issue_busy_pmc": valu_busy,
+                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS, "valu_issue_busy_pmc": valu_busy, "valu_pipe_busy_pmc": valu_pipe,
                          "rays_per_iteration_per_step": [x / args.steps for x in st["rays_per_iteration"][:8]],
                          "note": "achieved = algorithmic bytes (DESIGN.md section 4) / launch time; the 83 MB scene is served by L1/L2/"
                                  "Infinity Cache (traffic = HBM-side bytes per launch from the PMC passes is ~15% of the algorithmic "
-                                 "bytes), so frac near or above 1 means HBM is not the limiter: the kernel is VALU-issue bound "
-                                 "(VALU issue saturated, profiles/r01_pmc_summary_c5_1080p.json)"},
+                                 "bytes), so frac near or above 1 means HBM is not the limiter: the kernel is bound by latency and "
+                                 "instruction issue (VALU pipes 59% busy, waves 46% of their time at s_waitcnt; profiles/traffic.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)
