@@ -480,6 +480,45 @@ def test_single_primitives_and_odd_sizes(ctx):
             assert np.abs(rgb.astype(int) - want.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_soups_match_the_oracle(ctx, seed):
+    """Random mixtures of meshes (triangle sizes over three decades, slivers, interpenetrating, some
+    far away), spheres of very different radii and a plane: ids, t and normals of every primary ray
+    against the brute-force oracle.  Exercises leaves of one and two primitives, parked leaves, big
+    spheres outside the BVH and rays that miss everything."""
+    rng = np.random.default_rng(seed)
+    objs = []
+    for m in range(int(rng.integers(1, 4))):
+        nt = int(rng.integers(50, 1500))
+        centre = rng.uniform(-2.0, 2.0, size=(nt, 1, 3)) * np.array([1.0, 0.7, 1.5]) + np.array([0.0, 0.0, -1.0])
+        size = 10.0 ** rng.uniform(-2.5, 0.0, size=(nt, 1, 1))
+        verts = (centre + size * rng.normal(size=(nt, 3, 3))).reshape(-1, 3)
+        if m == 0:
+            verts[: 3 * (nt // 10)] *= np.array([1.0, 1.0, 1e-3])      # slivers squeezed into a plane
+        objs.append(dict(type="Mesh", verts=verts, tris=np.arange(3 * nt).reshape(nt, 3),
+                         materials=[dict(type="Lambertian", albedo=[0.5, 0.5, 0.5])]))
+    for k in range(int(rng.integers(0, 30))):
+        objs.append(dict(type="Sphere", center=list(rng.uniform(-2.5, 2.5, size=3)), radius=float(10.0 ** rng.uniform(-2.0, 0.3)),
+                         material=dict(type="Metal", albedo=[0.8, 0.8, 0.8], fuzziness=0.1)))
+    if seed % 2:
+        objs.append(dict(type="Sphere", center=[0.0, -500.5, 0.0], radius=498.0, material=dict(type="Lambertian", albedo=[0.3, 0.3, 0.3])))
+        objs.append(dict(type="Plane", center=[0.0, 0.0, -6.0], normal=[0.0, 0.2, 1.0], material=dict(type="Lambertian", albedo=[0.2, 0.2, 0.2])))
+    osc = small_scene(ctx, objs, 160, 120)
+    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    assert (want["object_id"] >= 0).mean() > 0.2
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=6, curved=True)
+    print("soup %d: %d objects, %d id mismatches of %d, max rel t %.2e" % (seed, len(objs), bad, got["t"].size, rt_))
+    # the same scene through the GPU-built BVH gives the same hits
+    ctx.set_bvh_builder("gpu")
+    try:
+        small_scene(ctx, objs, 160, 120)
+        got2 = ctx.primary_hits(0.5, 0.5)
+    finally:
+        ctx.set_bvh_builder("host")
+    for k in ("object_id", "triangle_id", "t"):
+        assert np.array_equal(got[k], got2[k]), k
+
+
 def test_tie_break_prefers_lower_object_index(ctx):
     """scene.rs:43 strict '>': two coincident emissive triangles / spheres -> the first object wins."""
     v = np.array([[-1.0, -1, 0], [1, -1, 0], [0, 1, 0]])
