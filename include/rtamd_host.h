@@ -42,6 +42,9 @@ void rt_host_camera(const double eye[3], const double look_at[3], const double u
 
 /* image::write_image (image.rs:149-163): RGB8 PNG, creates parent directories. */
 int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height, char* err, size_t err_len);
+/* No reference counterpart (the reference writes 8 bits only, image.rs:149-163): the same
+ * file layout with 16-bit samples, for the colour plane of rt_resolve quantised as (65535.999 * c) as u16. */
+int rt_host_write_png16(const char* path, const uint16_t* rgb16, uint32_t width, uint32_t height, char* err, size_t err_len);
 /* image::read_image (image.rs:166-184): 8-bit RGB PNG -> malloc'ed bytes (free with rt_host_free). */
 int rt_host_read_png(const char* path, uint8_t** rgb8, uint32_t* width, uint32_t* height, char* err, size_t err_len);
 void rt_host_free(void* p);

@@ -350,6 +350,20 @@ def write_png(path, rgb8):
         raise RtError(err.value.decode())
 
 
+def write_png16(path, color):
+    """16-bit RGB PNG of a colour plane in [0, 1] (`Context.resolve(...)[1]`, or gamma'd sample means):
+    (65535.999 * c) as u16, the 16-bit analogue of image.rs:37-43.  No reference counterpart."""
+    L = _lib.load_library()
+    c = np.asarray(color, dtype=np.float64)
+    if c.ndim != 3 or c.shape[2] != 3:
+        raise ValueError("expected an H x W x 3 array")
+    q = np.nan_to_num(65535.999 * c, nan=0.0, posinf=65535.0, neginf=0.0)
+    a = np.ascontiguousarray(np.clip(np.trunc(q), 0.0, 65535.0).astype(np.uint16))
+    err = C.create_string_buffer(512)
+    if L.rt_host_write_png16(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], err, 512):
+        raise RtError(err.value.decode())
+
+
 def read_png(path):
     L = _lib.load_library()
     p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()

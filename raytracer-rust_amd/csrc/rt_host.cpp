@@ -302,7 +302,8 @@ void read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, u
 }
 
 // image.rs:149-163
-void write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+// bytes_per_sample = 1: 8-bit RGB (what the reference writes); 2: 16-bit RGB, samples big-endian (PNG spec)
+void write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t bytes_per_sample = 1) {
     namespace fs = std::filesystem;
     fs::path pth(path);
     if (pth.has_parent_path()) {
@@ -310,7 +311,7 @@ void write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t
         fs::create_directories(pth.parent_path(), ec);   // image.rs:155-156
         if (ec) raise("cannot create directory '%s': %s", pth.parent_path().string().c_str(), ec.message().c_str());
     }
-    const size_t stride = (size_t)w * 3;
+    const size_t stride = (size_t)w * 3 * bytes_per_sample;
     std::vector<uint8_t> raw((stride + 1) * h);
     for (uint32_t y = 0; y < h; ++y) {
         raw[(stride + 1) * y] = 0;
@@ -329,7 +330,7 @@ void write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t
     };
     std::vector<uint8_t> ihdr;
     put32(ihdr, w); put32(ihdr, h);
-    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    ihdr.push_back((uint8_t)(8 * bytes_per_sample)); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
     chunk("IHDR", ihdr.data(), (uint32_t)ihdr.size());
     chunk("IDAT", comp.data(), (uint32_t)clen);
     chunk("IEND", nullptr, 0);
@@ -776,6 +777,19 @@ int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uin
     try {
         if (!path || !rgb8) raise("NULL argument");
         write_png(path, rgb8, width, height);
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, err_len, e.what());
+        return 1;
+    }
+}
+int rt_host_write_png16(const char* path, const uint16_t* rgb16, uint32_t width, uint32_t height, char* err, size_t err_len) {
+    try {
+        if (!path || !rgb16) raise("NULL argument");
+        const size_t nv = (size_t)width * height * 3;
+        std::vector<uint8_t> be(nv * 2);
+        for (size_t i = 0; i < nv; ++i) { be[2 * i] = (uint8_t)(rgb16[i] >> 8); be[2 * i + 1] = (uint8_t)(rgb16[i] & 0xFFu); }
+        write_png(path, be.data(), width, height, 2);
         return 0;
     } catch (const std::exception& e) {
         set_err(err, err_len, e.what());

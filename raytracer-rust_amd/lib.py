@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_render_accumulate", "rt_resolve",
     "rt_render_image", "rt_primary_hits", "rt_get_stats", "rt_stats_reset", "rt_debug_gather", "rt_context_set_bvh_builder", "rt_bvh_build_validate",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_desc", "rt_host_scene_num_objects", "rt_host_scene_object_kind",
-    "rt_host_ssaa_parse", "rt_host_camera", "rt_host_write_png", "rt_host_read_png", "rt_host_free", "rt_host_compute_image", "rt_host_compute_image_devices", "rt_host_bvh_validate",
+    "rt_host_ssaa_parse", "rt_host_camera", "rt_host_write_png", "rt_host_write_png16", "rt_host_read_png", "rt_host_free", "rt_host_compute_image", "rt_host_compute_image_devices", "rt_host_bvh_validate",
 ]
 
 
@@ -124,6 +124,8 @@ def load_library():
     L.rt_host_camera.argtypes = [vp, vp, vp, dbl, u32, u32, vp, vp, vp, vp]
     L.rt_host_write_png.restype = C.c_int
     L.rt_host_write_png.argtypes = [C.c_char_p, vp, u32, u32, C.c_char_p, C.c_size_t]
+    L.rt_host_write_png16.restype = C.c_int
+    L.rt_host_write_png16.argtypes = [C.c_char_p, vp, u32, u32, C.c_char_p, C.c_size_t]
     L.rt_host_read_png.restype = C.c_int
     L.rt_host_read_png.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32), C.c_char_p, C.c_size_t]
     L.rt_host_free.restype = None

@@ -128,6 +128,36 @@ def test_png_reader_matches_pillow_and_roundtrip(tmp_path):
         api.read_png(os.path.join(GOLDEN, "scenes/cube/cube.obj"))
 
 
+
+def test_png16_round_trip(tmp_path):
+    """16-bit output: checked with an independent decoder (zlib + struct)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(3)
+    color = rng.random((7, 5, 3))
+    color[0, 0] = [0.0, 1.0, 2.5]             # saturates like image.rs:37-43
+    out = tmp_path / "deep" / "c16.png"
+    api.write_png16(str(out), color)
+    raw = out.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (5, 7, 16, 2, 0, 0, 0)
+    rows = zlib.decompress(idat)
+    stride = 1 + 5 * 3 * 2
+    got = np.stack([np.frombuffer(rows[y * stride + 1:(y + 1) * stride], dtype=">u2").reshape(5, 3) for y in range(7)])
+    assert all(rows[y * stride] == 0 for y in range(7))
+    want = np.clip(np.trunc(65535.999 * color), 0, 65535).astype(np.uint16)
+    assert np.array_equal(got, want) and got[0, 0].tolist() == [0, 65535, 65535]
+
 def test_loader_errors_instead_of_panics(tmp_path):
     y = tmp_path / "s.yaml"
     base = "width: 4\nheight: 4\nbackground: [0,0,0]\ncamera:\n  eye: [0,0,0]\n  look_at: [0,0,-1]\n  up: [0,1,0]\n  fovy: 45\nobjects:\n"
