@@ -176,7 +176,7 @@ int rt_stats_reset(rt_context* ctx);
 
 /* No reference counterpart (the reference has one AABB per mesh, mesh.rs:318-326).
  * Chooses the builder of the BVH that rt_scene_upload makes: 0 = host, binned SAH, threaded (default;
- * best trees: 0.16 s for 1M triangles), 1 = GPU linear BVH (Morton codes, radix sort, Karras tree,
+ * best trees: 0.2 s for 1M triangles), 1 = GPU linear BVH (Morton codes, radix sort, Karras tree,
  * collapse to the same 4-wide quantised nodes; milliseconds, more nodes per ray). */
 int rt_context_set_bvh_builder(rt_context* ctx, int builder);
 
