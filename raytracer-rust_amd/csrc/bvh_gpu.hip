@@ -121,9 +121,8 @@ __device__ __forceinline__ float box_half_area(const float b[6]) {
 }
 // cost of child c of a node for 1..4 slots: a leaf costs area * primitives whatever it is given
 __device__ __forceinline__ void child_cost(const Tree& t, int c, const float b[6], float out[4]) {
-    const uint32_t size = kid_size(t, c);
-    if (c < 0 || size <= MAX_LEAF_PRIMS) {
-        const float v = box_half_area(b) * (float)size;
+    if (c < 0) {
+        const float v = box_half_area(b);
         out[0] = out[1] = out[2] = out[3] = v;
     } else {
         for (int k = 0; k < 4; ++k) out[k] = t.cost[4 * (size_t)c + k];   // written before c's (fenced) arrival here
@@ -151,14 +150,17 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const uint32_t* __restrict__
             t.box[6 * (size_t)p + k] = m[k];
             t.box[6 * (size_t)p + 3 + k] = m[3 + k];
         }
-        // the collapse tables of bvh.cpp (dynamic programming on the SAH cost, a node step = two primitive steps)
+        // the collapse tables of bvh.cpp (dynamic programming on the SAH cost, a node step = 1.5 primitive steps)
         float as_node = INFINITY;
         uint8_t pn = 1;
         for (int i = 1; i <= 3; ++i) {
             const float c = cl[i - 1] + cr[3 - i];
             if (c < as_node) { as_node = c; pn = (uint8_t)i; }
         }
-        as_node += 2.0f * box_half_area(m);
+        as_node += 1.5f * box_half_area(m);
+        // at most MAX_LEAF_PRIMS primitives below: in ONE slot the subtree is a leaf, never a wide node
+        const uint32_t psize = kid_size(t, p);
+        if (psize <= MAX_LEAF_PRIMS) as_node = box_half_area(m) * (float)psize;
         t.part_node[p] = pn;
         t.cost[4 * (size_t)p] = as_node; t.part[4 * (size_t)p] = 0;
         for (int k = 2; k <= 4; ++k) {
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const uint32_t* __restric
         todo_node[nt] = t.left[it.node]; todo_k[nt++] = pn;
         while (nt > 0 && nk < 4) {
             const int c = todo_node[--nt], k = todo_k[nt];
-            const int li = (c < 0 || kid_size(t, c) <= MAX_LEAF_PRIMS) ? 0 : (int)t.part[4 * (size_t)c + k - 1];
+            const int li = c < 0 ? 0 : (int)t.part[4 * (size_t)c + k - 1];   // a small subtree may stay one leaf or hand its primitives to free slots
             if (li <= 0 || li >= k || nt > 5) { kids[nk++] = c; continue; }   // one child (leaf or wide node)
             todo_node[nt] = t.right[c]; todo_k[nt++] = k - li;
             todo_node[nt] = t.left[c]; todo_k[nt++] = li;
