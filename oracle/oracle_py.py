@@ -184,6 +184,15 @@ def load_scene_dict(yaml_path, base_dir=None):
             p = os.path.normpath(os.path.join(base, o["path"]))
             meshes = load_obj(p)
             m = meshes[0]  # scene.rs:170
+            if o.get("all_objects") is True:   # additive key: the other `o` objects are appended to the first
+                for extra in meshes[1:]:
+                    v0, u0, m0 = len(m["verts"]), len(m["uvs"]), len(m["mat_names"])
+                    m["tris"] += [tuple(i + v0 for i in t) for t in extra["tris"]]
+                    m["uv_idx"] += [None if u is None else tuple(i + u0 for i in u) for u in extra["uv_idx"]]
+                    m["tri_mat"] += [k + m0 if k >= 0 else k for k in extra["tri_mat"]]
+                    m["verts"] += extra["verts"]
+                    m["uvs"] += extra["uvs"]
+                    m["mat_names"] += extra["mat_names"]
             mats = []
             for name in m["mat_names"]:
                 md = dict(o["materials"][name])

@@ -655,7 +655,30 @@ std::unique_ptr<rt_host_scene> load_scene(const std::string& yaml_path, const st
             for (auto& kv : mats->map) mm[kv.first] = parse_material(kv.second);
             std::vector<MeshH> meshes = load_obj(path, mm);
             if (meshes.empty()) raise("object %d: '%s' holds no 'o' object (the reference panics, scene.rs:170)", oi, path.c_str());
-            MeshH& mesh = meshes[0];                                 // only the FIRST object is kept, scene.rs:170
+            // Only the FIRST object of the file is kept (scene.rs:170).  Additive key `all_objects: true` (SURVEY
+            // 8f-2; the reference's serde model ignores unknown keys): the file's other `o` objects are appended
+            // to the first, so the whole file is one scene object with triangle ids in file order.
+            if (const Node* all = o.get("all_objects")) {
+                const std::string v = as_str(all, "all_objects");
+                if (v == "true" || v == "True" || v == "yes") {
+                    for (size_t mi = 1; mi < meshes.size(); ++mi) {
+                        MeshH& src = meshes[mi];
+                        const uint64_t v0 = meshes[0].positions.size() / 3, u0 = meshes[0].uvs.size() / 2;
+                        const int64_t m0 = (int64_t)meshes[0].materials.size();
+                        for (TriangleH t : src.triangles) {
+                            for (int k = 0; k < 3; ++k) { t.v[k] += v0; if (t.has_uv) t.uv[k] += u0; }
+                            if (t.material_idx >= 0) t.material_idx += m0;
+                            meshes[0].triangles.push_back(t);
+                        }
+                        meshes[0].positions.insert(meshes[0].positions.end(), src.positions.begin(), src.positions.end());
+                        meshes[0].uvs.insert(meshes[0].uvs.end(), src.uvs.begin(), src.uvs.end());
+                        meshes[0].materials.insert(meshes[0].materials.end(), src.materials.begin(), src.materials.end());
+                    }
+                } else if (v != "false" && v != "False" && v != "no") {
+                    raise("object %d: all_objects: expected true or false", oi);
+                }
+            }
+            MeshH& mesh = meshes[0];
             // Scene::precompute, scene.rs:56-66: textures of mesh materials
             std::vector<int> global_mat;
             for (MaterialH& m : mesh.materials) {

@@ -195,6 +195,30 @@ def test_obj_quirks(tmp_path):
     assert len(got) == 2 and got[1]["tris"] == [(0, 1, 2)]
 
 
+def test_all_objects_key_keeps_every_o_of_the_file(tmp_path):
+    """Additive YAML key `all_objects: true` (serde ignores it in the reference): the other
+    `o` objects are appended to the first, indices stay global to the file, both loaders agree."""
+    obj = tmp_path / "m.obj"
+    obj.write_text("o A\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl M\nf 1/1 2/2 3/3\n"
+                   "o B\nv 5 5 5\nv 6 5 5\nv 5 6 5\nvt 0.5 0.5\nvt 1 0.5\nvt 0.5 1\nusemtl N\nf 4/4 5/5 6/6\nf 6/6 5/5 4/4\n")
+    for flag, ntri in (("", 1), ("    all_objects: false\n", 1), ("    all_objects: true\n", 3)):
+        y = tmp_path / "s.yaml"
+        y.write_text("width: 4\nheight: 4\nbackground: [0, 0, 0]\ncamera:\n  eye: [0,0,3]\n  look_at: [0,0,0]\n  up: [0,1,0]\n  fovy: 45\n"
+                     "objects:\n  - type: Mesh\n    path: %s\n%s    materials:\n      M:\n        type: Emissive\n        color: [1, 1, 1]\n"
+                     "      N:\n        type: Lambertian\n        albedo: [0.5, 0.25, 0.125]\n" % (obj, flag))
+        a = rt.Scene.load(str(y)).arrays()
+        d = O.load_scene_dict(str(y))
+        m = d["objects"][0]["mesh"]
+        assert len(a["tri_index"]) == ntri == len(m["tris"])
+        assert np.array_equal(a["tri_vertices"], np.array(m["verts"])[np.array(m["tris"])])
+        assert np.array_equal(a["tri_uv"], np.array(m["uvs"])[np.array(m["uv_idx"])])
+        assert a["tri_index"].tolist() == list(range(ntri)) and np.all(a["tri_object"] == 0)
+        if ntri == 3:
+            assert a["tri_vertices"][2].tolist() == [[5, 6, 5], [6, 5, 5], [5, 5, 5]]
+            assert a["tri_material"][0] != a["tri_material"][1] == a["tri_material"][2]
+            assert m["tri_mat"] == [0, 1, 1] and m["mat_names"] == ["M", "N"]
+
+
 def test_scenegen_roundtrip_through_yaml_and_obj(tmp_path):
     sc = scenegen.scene_c5(width=64, height=36, nu=24, nv=12)
     direct = rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]).arrays()
