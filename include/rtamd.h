@@ -113,7 +113,9 @@ typedef struct rt_render_params {
     uint32_t sample_end;     /* (anti_aliasing.rs:96-100); end = 0 means N*N             */
     uint32_t tile_index;     /* 8x8-pixel tiles are dealt round-robin: this call renders */
     uint32_t tile_count;     /* tiles t with t % tile_count == tile_index; 0 means 1     */
-    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths = 17 GB of queues)     */
+    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths = 17 GB of queues; less */
+                                     /* with more than 4 lights: a queue holds one ray per */
+                                     /* light and path)                                    */
     uint32_t max_shadow_generations; /* cap of the shadow-ray branching process          */
                                      /* (raytrace.rs:78-85 recursion); 0 = default 16    */
     uint32_t flags;          /* rt_render_flags                                          */
@@ -150,6 +152,21 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* scene);
  * Asynchronous on `stream` (a hipStream_t, NULL = default stream). */
 int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, float* accum_dev, void* stream);
 
+/* No counterpart in the reference (which allocates freely, e.g. one Vec per pixel, anti_aliasing.rs:95).
+ * rt_render_accumulate for callers that CANNOT allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same result; the wavefront state
+ * (control block, two ray queues, hit records, sample radiance) lives in a static device array of
+ * RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, and the call
+ * makes no hipMalloc / hipFree / event creation.  Limits, all reported as errors:
+ *  - the call is ONE pass: paths = (tiles of the call) * 64 * (samples of the call) must satisfy
+ *    12 KiB + paths * (16 + 104 * max(1, n_lights)) bytes <= RT_NOALLOC_SCRATCH_BYTES (about 559,000 paths
+ *    without lights, 299,000 with two); split larger frames over several calls by sample range or tile set;
+ *  - RT_FLAG_TIMING is refused (it creates events).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two contexts, two streams)
+ * race; calls in one stream are ordered.  Asynchronous on `stream` like rt_render_accumulate. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_accumulate_noalloc(rt_context* ctx, const rt_render_params* params, float* accum_dev, void* stream);
+
 /* raytrace.rs:144-150 + image.rs:29-43: mean over spp_total, sqrt, clamp to <= 1,
  * trunc(255.999*c) saturating.  Either output may be NULL.  Device pointers. */
 int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t spp_total, uint8_t* rgb8_dev, float* color_dev, void* stream);
@@ -157,11 +174,14 @@ int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t spp_total, uint
 /* Whole pixel loop of compute_image (raytrace.rs:126-154) with host outputs
  * (either may be NULL): accum_host = per-pixel sum of sample colours (float),
  * rgb8_host = the bytes write_image would store (image.rs:128-135). Synchronous.
- * Fails (after filling the outputs) if rays were dropped because a queue was full: only the
- * branching shadow-ray process of scenes with more than ~4 lights can do that
- * (raytrace.rs:78-85 spawns L rays per firing path and each can fire again; the reference
- * itself recurses without bound there).  rt_render_accumulate is asynchronous and reports the
- * same count through rt_get_stats().queue_overflow. */
+ * Fails (after filling the outputs) if rays were dropped because a queue was full.  A queue holds
+ * n_lights rays per path of the pass, so the shadow rays of the last bounce always fit; only the
+ * branching process after it can overflow, in scenes with 4 or more lights where every shadow ray
+ * has more than one successor on average (raytrace.rs:78-85 spawns L rays per firing path and each
+ * can fire again with probability 0.1 L; the reference itself recurses without bound there).
+ * Whether that happens depends on the call's parameters only, not on what the context rendered
+ * before; max_shadow_generations cuts the process off.  rt_render_accumulate is asynchronous and
+ * reports the same count through rt_get_stats().queue_overflow. */
 int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accum_host, uint8_t* rgb8_host);
 
 /* Closest hit of ONE primary ray per pixel at sub-pixel offset (dx,dy)
@@ -170,9 +190,36 @@ int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accu
  * triangle_id = -1 for spheres and planes.  Synchronous. */
 int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, int32_t* triangle_id, float* t, float* normal_xyz);
 
+/* The device's own primary rays for the same sample position as rt_primary_hits: origin (3 floats, the eye)
+ * and one unit direction per pixel (height*width*3 floats, host), exactly the f32 values k_raygen hands to the
+ * closest-hit kernel (camera.rs:62-67 in f64, rounded once).  Lets the parity tests feed the oracle the very
+ * rays the device traced, so that the 1e-5 gate on t and normal holds for every hit.  Synchronous. */
+int rt_primary_rays(rt_context* ctx, double dx, double dy, float origin_xyz[3], float* dir_xyz);
+
 /* Counters since the last rt_stats_reset (synchronises the context's streams). */
 int rt_get_stats(rt_context* ctx, rt_stats* out);
 int rt_stats_reset(rt_context* ctx);
+
+/* ---- several GPUs from one process.  No reference counterpart: raytrace.rs:126-154 is one process on one
+ * machine.  (bench.py's one-process-per-GPU path uses torch.distributed/RCCL for the same exchange.) ---- */
+
+/* rt_scene_upload to n contexts (one per GPU): the scene is flattened and its BVH built ONCE (with ctxs[0]'s
+ * builder), then copied to every context's GPU.  On error the message is on ctxs[0]. */
+int rt_scene_upload_devices(rt_context* const* ctxs, uint32_t n, const rt_scene_desc* scene);
+
+/* The exchange step of the sample / tile split, on the GPUs: dst_accum_dev (on dst's GPU) += each
+ * src_accum_dev[k] (on src[k]'s GPU; height*width*3 floats).  A partial frame on another GPU comes over with one
+ * peer copy (hipMemcpyPeerAsync: xGMI when peer access is available) into a landing buffer on dst's GPU,
+ * followed by an add kernel; nothing passes through host memory.  Asynchronous on `stream` of dst's GPU; the
+ * sources must be complete (synchronise their streams first). */
+int rt_accum_reduce(rt_context* dst, float* dst_accum_dev, rt_context* const* src, const float* const* src_accum_dev, uint32_t n_src, void* stream);
+
+/* rt_render_image on n contexts that hold the same scene: split_tiles = 0 splits the samples of the call into
+ * contiguous ranges (same RNG keys as one device), 1 deals the call's 8x8 tiles round-robin; one host thread
+ * per context renders, then rt_accum_reduce sums the partial frames on ctxs[0]'s GPU, rt_resolve runs there
+ * and the result is copied to the host once.  Outputs as rt_render_image. */
+int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render_params* params, int split_tiles, float* accum_host,
+                            uint8_t* rgb8_host);
 
 /* No reference counterpart (the reference has one AABB per mesh, mesh.rs:318-326).
  * Chooses the builder of the BVH that rt_scene_upload makes: 0 = host, binned SAH, threaded (default;

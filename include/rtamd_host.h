@@ -61,9 +61,11 @@ int rt_host_compute_image(const char* ssaa, uint32_t depth, const char* scene_pa
                           int device_id, uint64_t seed, char* err, size_t err_len);
 
 /* The same on n_devices GPUs from one process (additive flags of SURVEY 8b: --devices, --split): one
- * context and host thread per device; split_tiles = 0 splits the N*N samples (disjoint ranges, the
- * same RNG keys a single device would use), 1 deals the 8x8 tiles round-robin; the partial sums are
- * added on the host in device order and resolved as raytrace.rs:144-150 / image.rs:37-43 do. */
+ * context and host thread per device, the scene flattened and its BVH built once
+ * (rt_scene_upload_devices); split_tiles = 0 splits the N*N samples (disjoint ranges, the same RNG
+ * keys a single device would use), 1 deals the 8x8 tiles round-robin; the partial frames are summed
+ * on the first GPU over peer copies and resolved there as raytrace.rs:144-150 / image.rs:37-43 do
+ * (rt_render_image_devices); nothing but the final RGB8 frame passes through host memory. */
 int rt_host_compute_image_devices(const char* ssaa, uint32_t depth, const char* scene_path, const char* output_path, const char* base_dir,
                                   const int* device_ids, uint32_t n_devices, int split_tiles, uint64_t seed, char* err, size_t err_len);
 

@@ -46,6 +46,7 @@ def lib():
         L.orc_add_mesh.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p,
                                    C.c_void_p, C.c_long, C.c_void_p]
         L.orc_prepare.argtypes = [C.c_void_p]
+        L.orc_enable_accel.argtypes = [C.c_void_p, C.c_int]
         L.orc_num_lights.restype = C.c_int
         L.orc_num_lights.argtypes = [C.c_void_p]
         L.orc_light_points.restype = C.c_int
@@ -56,6 +57,7 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_closest_hit.restype = C.c_int
         L.orc_closest_hit.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.orc_closest_hits.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.orc_render.restype = C.c_uint64
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint64, C.c_int, C.c_long, C.c_long, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
@@ -215,6 +217,7 @@ class OracleScene:
         self.h = L.orc_scene_new(prec, self.width, self.height, _d3(background), _d3(camera["eye"]), _d3(camera["look_at"]),
                                  _d3(camera["up"]), float(camera["fovy"]))
         self._keep = []
+        self.prec = prec
         self.prepared = False
 
     def __del__(self):
@@ -267,8 +270,14 @@ class OracleScene:
         self.prepared = True
         return self
 
+    def enable_accel(self, on=True):
+        """Conservative cull in front of every mesh's triangle loop (rt_oracle.cpp header): the same results, bit for bit,
+        without testing all triangles.  Test infrastructure for full-size scenes; never on for the timed cpu_baseline."""
+        self.L.orc_enable_accel(self.h, 1 if on else 0)
+        return self
+
     @classmethod
-    def from_dict(cls, d, prec=0):
+    def from_dict(cls, d, prec=0, accel=False):
         sc = cls(d["width"], d["height"], d["background"], d["camera"], prec=prec)
         for o in d["objects"]:
             if o["type"] == "Sphere":
@@ -285,7 +294,8 @@ class OracleScene:
                                 m["uv_idx"] if has_uv else None)
             else:
                 raise ValueError(o["type"])
-        return sc.prepare()
+        sc.prepare()
+        return sc.enable_accel() if accel else sc
 
     @classmethod
     def from_yaml(cls, path, base_dir=None, prec=0):
@@ -335,6 +345,23 @@ class OracleScene:
         if not ok:
             return None
         return dict(object_id=obj.value, triangle_id=tri.value, t=t.value, point=pt, normal=nrm, uv=uv)
+
+    def closest_hits(self, origins, dirs, threads=None):
+        """Closest hits of arbitrary rays (f64 oracle): origins (3,) or (..., 3), dirs (..., 3); returns arrays shaped like dirs[..., 0]."""
+        assert self.prec == 0
+        dd = np.ascontiguousarray(dirs, dtype=np.float64)
+        shp = dd.shape[:-1]
+        dd = dd.reshape(-1, 3)
+        oo = np.ascontiguousarray(np.broadcast_to(np.asarray(origins, dtype=np.float64).reshape(-1, 3) if np.ndim(origins) > 1 else
+                                                  np.asarray(origins, dtype=np.float64), dd.shape))
+        n = len(dd)
+        obj, tri = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        t, nrm, pt = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3))
+        if threads is None:
+            threads = min(os.cpu_count() or 1, 16)
+        self.L.orc_closest_hits(self.h, n, _p(oo), _p(dd), int(threads), _p(obj), _p(tri), _p(t), _p(nrm), _p(pt))
+        return dict(object_id=obj.reshape(shp), triangle_id=tri.reshape(shp), t=t.reshape(shp), normal=nrm.reshape(shp + (3,)),
+                    point=pt.reshape(shp + (3,)))
 
     def render(self, mode="jitter", N=2, depth=5, seed=1, threads=None, s_begin=0, s_end=-1):
         """Returns dict(sum, color, rgb8, rays). sum = per-pixel sum of sample colours."""

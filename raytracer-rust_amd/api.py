@@ -287,6 +287,15 @@ class Context:
         p = params.to_c()
         self._check(self._L.rt_render_accumulate(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), C.c_void_p(st)))
 
+    def render_accumulate_noalloc(self, params, accum, stream=None):
+        """rt_render_accumulate_noalloc: one pass in the library's static scratch array, no device allocation."""
+        import torch
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.numel() == self.width * self.height * 3
+        assert accum.device.index == self.device
+        st = stream if stream is not None else torch.cuda.current_stream(accum.device).cuda_stream
+        p = params.to_c()
+        self._check(self._L.rt_render_accumulate_noalloc(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), C.c_void_p(st)))
+
     def resolve(self, accum, spp_total, want_color=False, stream=None):
         import torch
         st = stream if stream is not None else torch.cuda.current_stream(accum.device).cuda_stream
@@ -312,6 +321,13 @@ class Context:
         self._check(self._L.rt_primary_hits(self._h, float(dx), float(dy), obj.ctypes.data, tri.ctypes.data, t.ctypes.data, nrm.ctypes.data))
         shp = (self.height, self.width)
         return dict(object_id=obj.reshape(shp), triangle_id=tri.reshape(shp), t=t.reshape(shp), normal=nrm.reshape(shp + (3,)))
+
+    def primary_rays(self, dx=0.0, dy=0.0):
+        """The device's own f32 primary rays at the sample position of primary_hits: (origin (3,), directions (H, W, 3))."""
+        o = np.zeros(3, np.float32)
+        d = np.zeros((self.height, self.width, 3), np.float32)
+        self._check(self._L.rt_primary_rays(self._h, float(dx), float(dy), o.ctypes.data, d.ctypes.data))
+        return o, d
 
     def stats(self):
         s = _lib.StatsC()
@@ -340,6 +356,43 @@ class Context:
         t = C.c_double(0.0)
         self._check(self._L.rt_bvh_build_validate(self._h, b.shape[0], b.ctypes.data, C.byref(nn), C.byref(dd), C.byref(ms), C.byref(t)))
         return dict(nodes=nn.value, depth=dd.value, max_stack=ms.value, build_ms=t.value)
+
+
+def _ctx_array(contexts):
+    return (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+
+
+def upload_devices(contexts, scene):
+    """rt_scene_upload_devices: one flatten + BVH build, one copy per context."""
+    L = _lib.load_library()
+    d = scene.desc
+    if L.rt_scene_upload_devices(_ctx_array(contexts), len(contexts), C.byref(d)):
+        raise RtError(L.rt_last_error(contexts[0]._h).decode())
+    for c in contexts:
+        c.scene, c.width, c.height = scene, d.width, d.height
+
+
+def render_image_devices(contexts, params, split="spp"):
+    """rt_render_image_devices: the call's samples (split="spp") or tiles (split="tiles") shared by the contexts,
+    partial frames summed on the first context's GPU.  Returns (accum float32 (H,W,3), rgb8 (H,W,3))."""
+    L = _lib.load_library()
+    c0 = contexts[0]
+    acc = np.zeros((c0.height, c0.width, 3), np.float32)
+    rgb = np.zeros((c0.height, c0.width, 3), np.uint8)
+    p = params.to_c()
+    if L.rt_render_image_devices(_ctx_array(contexts), len(contexts), C.byref(p), 1 if split == "tiles" else 0, acc.ctypes.data, rgb.ctypes.data):
+        raise RtError(L.rt_last_error(c0._h).decode())
+    return acc, rgb
+
+
+def accum_reduce(dst_ctx, dst_accum, src_contexts, src_accums, stream=None):
+    """rt_accum_reduce on torch tensors: dst_accum += each src_accums[k] (each on its context's GPU)."""
+    import torch
+    L = _lib.load_library()
+    st = stream if stream is not None else torch.cuda.current_stream(dst_accum.device).cuda_stream
+    ptrs = (C.c_void_p * len(src_accums))(*[a.data_ptr() for a in src_accums])
+    if L.rt_accum_reduce(dst_ctx._h, C.c_void_p(dst_accum.data_ptr()), _ctx_array(src_contexts), ptrs, len(src_accums), C.c_void_p(st)):
+        raise RtError(L.rt_last_error(dst_ctx._h).decode())
 
 
 def write_png(path, rgb8):

@@ -17,7 +17,6 @@ namespace rtamd {
 namespace {
 
 constexpr int kBins = 16;
-static uint32_t kMaxLeaf = MAX_LEAF_PRIMS;           // primitives per leaf (the leaf encoding allows 8)
 constexpr uint32_t kMedianDepth = 40;   // beyond this depth fall back to median splits (bounds the depth)
 
 struct Box {
@@ -46,7 +45,8 @@ struct Builder {
     const std::vector<PrimBox>& prims;
     std::vector<uint32_t>& order;
     std::vector<float> cx, cy, cz;   // centroids
-    explicit Builder(const std::vector<PrimBox>& p, std::vector<uint32_t>& o) : prims(p), order(o) {
+    uint32_t max_leaf;               // primitives per leaf of the binary tree (the leaf encoding allows 8)
+    Builder(const std::vector<PrimBox>& p, std::vector<uint32_t>& o, uint32_t max_leaf_) : prims(p), order(o), max_leaf(max_leaf_) {
         size_t n = p.size();
         cx.resize(n); cy.resize(n); cz.resize(n);
         for (size_t i = 0; i < n; ++i) {
@@ -59,7 +59,7 @@ struct Builder {
 
     // Splits [first, first+count) in place; returns the size of the left part (0 = make a leaf).
     uint32_t split(uint32_t first, uint32_t count, uint32_t depth) {
-        if (count <= kMaxLeaf) return 0;
+        if (count <= max_leaf) return 0;
         uint32_t* idx = order.data() + first;
         Box cb; cb.reset();
         for (uint32_t i = 0; i < count; ++i) { float c[3] = {cx[idx[i]], cy[idx[i]], cz[idx[i]]}; cb.grow(c, c); }
@@ -194,9 +194,9 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
     // The binary tree is split down to single primitives; the collapse below decides which pairs stay one
     // leaf of two (MAX_LEAF_PRIMS) and which become two leaves in free slots of their parent.
     bool leaf_dp = true;
-    kMaxLeaf = 1;
-    if (const char* e = getenv("RTAMD_MAX_LEAF")) { kMaxLeaf = (uint32_t)std::min(8, std::max(1, atoi(e))); leaf_dp = false; }   // tuning experiments only: fixed leaf size
-    Builder B(boxes, out.order);
+    uint32_t max_leaf = 1;
+    if (const char* e = getenv("RTAMD_MAX_LEAF")) { max_leaf = (uint32_t)std::min(8, std::max(1, atoi(e))); leaf_dp = false; }   // tuning experiments only: fixed leaf size
+    Builder B(boxes, out.order, max_leaf);
     std::vector<TmpNode> tmp;
     if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 

@@ -17,7 +17,7 @@ static void usage(FILE* f) {
                "    -d, --depth <DEPTH>                [default: 5]\n    -o, --output-path <OUTPUT_PATH>\n"
                "    -s, --scene-path <SCENE_PATH>\n        --ssaa <SSAA>                  [default: uniform:2]\n"
                "        --device <ID>                  [default: 0]\n        --devices <ID,ID,...>          several GPUs, one context each\n"
-               "        --split <spp|tiles>            how --devices share the frame [default: spp]\n        --seed <SEED>                  [default: 0]\n"
+               "        --split <spp|tiles>            how --devices share the frame [default: spp]\n        --seed <SEED>                  RNG seed; renders are repeatable (the reference seeds from the OS) [default: 0]\n"
                "        --base-dir <DIR>\n    -h, --help\n");
 }
 

@@ -1,13 +1,16 @@
 // C-ABI of the render path (include/rtamd.h): context, scene upload (f64 -> device
 // layout + BVH), the wavefront loop and the statistics.  No torch types, no exceptions
 // across the boundary.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtamd.h"
@@ -19,6 +22,15 @@ using namespace rtamd;
 static_assert(RT_MAX_ITERATIONS == CTL_MAX_IT, "iteration table sizes must agree");
 
 static thread_local std::string g_global_error;
+
+// Scratch of rt_render_accumulate_noalloc (rtamd.h): the wavefront state of ONE pass -- control block,
+// two ray queues, hit records, sample radiance -- for callers that must not allocate (HIP graph capture,
+// serving loops).  Every GPU the library runs on holds its own copy of this array until the process ends.
+// The name is a host-side stand-in, not a device address: rt_context_create asks the runtime for the
+// address on its device (hipGetSymbolAddress) and only that pointer is ever handed to kernels or memsets.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[256] = {};      // per device
 
 struct DevBuf {
     void* p = nullptr;
@@ -49,6 +61,12 @@ struct rt_context {
     unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 3 words
     uint64_t paths_total = 0;
     uint64_t rays0_total = 0;   // primary rays actually traced (iteration 0)
+
+    // multi-GPU exchange step (rt_accum_reduce, rt_render_image_devices): grown on demand
+    float* own_accum = nullptr;    // this context's partial frame
+    float* staging = nullptr;      // landing buffer of peer copies
+    size_t own_accum_values = 0, staging_values = 0;
+    void* scratch_ptr = nullptr;   // device address of `scratch` on this context's GPU
 
     // timing of closest-hit launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -117,11 +135,6 @@ void free_state(rt_context* ctx) {
 }
 
 int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
-    if (!ctx->ctl) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->ctl, CTL_WORDS * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->stats_dev, (CTL_MAX_IT + 3) * sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 3) * sizeof(unsigned long long)));
-    }
     if (capacity > ctx->capacity || paths > ctx->path_capacity) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         free_state(ctx);
@@ -180,6 +193,21 @@ int rt_context_create(int device_id, rt_context** out) {
     DeviceGuard g(device_id);
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    // control block and statistics live as long as the context (no entry point allocates them later)
+    e = hipMalloc((void**)&ctx->ctl, CTL_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->stats_dev, (CTL_MAX_IT + 3) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 3) * sizeof(unsigned long long));
+    if (e != hipSuccess) { rt_context_destroy(ctx); return fail(nullptr, "hipMalloc: %s", hipGetErrorString(e)); }
+    {   // device address of the no-alloc scratch array, once per device, with that device current
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (device_id < (int)(sizeof(g_scratch_ptr) / sizeof(g_scratch_ptr[0])) && !g_scratch_ptr[device_id]) {
+            void* ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) { rt_context_destroy(ctx); return fail(nullptr, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
+            g_scratch_ptr[device_id] = ptr;
+        }
+        ctx->scratch_ptr = device_id < (int)(sizeof(g_scratch_ptr) / sizeof(g_scratch_ptr[0])) ? g_scratch_ptr[device_id] : nullptr;
+    }
     *out = ctx;
     return 0;
 }
@@ -192,32 +220,59 @@ void rt_context_destroy(rt_context* ctx) {
     free_state(ctx);
     (void)hipFree(ctx->ctl);
     (void)hipFree(ctx->stats_dev);
+    (void)hipFree(ctx->own_accum);
+    (void)hipFree(ctx->staging);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
-int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
-    if (!ctx) return fail(nullptr, "ctx is NULL");
-    if (!d) return fail(ctx, "scene is NULL");
-    if (d->width == 0 || d->height == 0) return fail(ctx, "width and height must be non-zero");
-    if ((uint64_t)d->width * d->height > (1ull << 31)) return fail(ctx, "image too large");
-    if (d->n_triangles + d->n_spheres >= (1ull << 28)) return fail(ctx, "too many primitives (limit 2^28)");
-    if (d->n_planes >= (1u << 20)) return fail(ctx, "too many planes");
-    auto bad_mat = [&](int32_t m) { return m < 0 || (uint32_t)m >= d->n_materials; };
-    for (uint32_t i = 0; i < d->n_spheres; ++i) if (bad_mat(d->sphere_material[i])) return fail(ctx, "sphere %u: material index out of range", i);
-    for (uint32_t i = 0; i < d->n_planes; ++i) if (bad_mat(d->plane_material[i])) return fail(ctx, "plane %u: material index out of range", i);
-    for (uint64_t i = 0; i < d->n_triangles; ++i)
-        if (bad_mat(d->tri_material[i])) return fail(ctx, "triangle %llu: material index out of range (a face before any usemtl?)", (unsigned long long)i);
-    for (uint32_t i = 0; i < d->n_materials; ++i) {
-        if (d->mat_type[i] < 0 || d->mat_type[i] > 4) return fail(ctx, "material %u: unknown type %d", i, d->mat_type[i]);
-        if (d->mat_type[i] == RT_MAT_TEXTURE && (d->mat_texture[i] < 0 || (uint32_t)d->mat_texture[i] >= d->n_textures))
-            return fail(ctx, "material %u: texture index out of range", i);
-    }
-    DeviceGuard g(ctx->device);
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    free_scene(ctx);
+}  // extern "C" (reopened below)
 
+// Host-side image of one scene in the device layout (rt_device.h): flattened and its BVH built ONCE,
+// then copied to any number of contexts (rt_scene_upload_devices).
+struct FlatScene {
+    std::vector<float4> nodes, prims, smeta, planes, mats, lights;
+    std::vector<int4> meta, textures;
+    std::vector<float> uvs;
+    std::vector<int32_t> plane_obj;
+    std::vector<uchar4> texels;
+    uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0;
+    float bg[3], eye[3];
+    double lle[3], hz[3], vt[3];
+    uint32_t width = 0, height = 0, stack_depth = 2, bvh_depth = 0;
+    double bvh_build_ms = 0;
+};
+
+// what the reference's `unwrap()`s would panic on, and what would make this library read out of bounds
+static int validate_desc(const rt_scene_desc* d, std::string& err) {
+    char buf[256];
+    auto bad = [&](const char* fmt, unsigned long long i) { snprintf(buf, sizeof(buf), fmt, i); err = buf; return 1; };
+    if (d->width == 0 || d->height == 0) { err = "width and height must be non-zero"; return 1; }
+    if ((uint64_t)d->width * d->height > (1ull << 31)) { err = "image too large"; return 1; }
+    if (d->n_triangles + d->n_spheres >= (1ull << 28)) { err = "too many primitives (limit 2^28)"; return 1; }
+    if (d->n_planes >= (1u << 20)) { err = "too many planes"; return 1; }
+    if (d->n_materials && (!d->mat_type || !d->mat_rgb || !d->mat_param)) { err = "material arrays are NULL"; return 1; }
+    if (d->n_textures && (!d->tex_width || !d->tex_height || !d->tex_rgb8)) { err = "texture arrays are NULL"; return 1; }
+    if (d->n_spheres && (!d->sphere_center || !d->sphere_radius || !d->sphere_material || !d->sphere_object)) { err = "sphere arrays are NULL"; return 1; }
+    if (d->n_planes && (!d->plane_center || !d->plane_normal || !d->plane_material || !d->plane_object)) { err = "plane arrays are NULL"; return 1; }
+    if (d->n_triangles && (!d->tri_vertices || !d->tri_material || !d->tri_object || !d->tri_index)) { err = "triangle arrays are NULL"; return 1; }
+    if (d->n_lights && !d->light_point) { err = "light_point is NULL"; return 1; }
+    auto bad_mat = [&](int32_t m) { return m < 0 || (uint32_t)m >= d->n_materials; };
+    for (uint32_t i = 0; i < d->n_spheres; ++i) if (bad_mat(d->sphere_material[i])) return bad("sphere %llu: material index out of range", i);
+    for (uint32_t i = 0; i < d->n_planes; ++i) if (bad_mat(d->plane_material[i])) return bad("plane %llu: material index out of range", i);
+    for (uint64_t i = 0; i < d->n_triangles; ++i)
+        if (bad_mat(d->tri_material[i])) return bad("triangle %llu: material index out of range (a face before any usemtl?)", i);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        if (d->mat_type[i] < 0 || d->mat_type[i] > 4) return bad("material %llu: unknown type", i);
+        if (d->mat_type[i] == RT_MAT_TEXTURE && (!d->mat_texture || d->mat_texture[i] < 0 || (uint32_t)d->mat_texture[i] >= d->n_textures))
+            return bad("material %llu: texture index out of range", i);
+    }
+    return 0;
+}
+
+// f64 scene -> device layout + BVH (built with ctx's builder; the GPU builder runs on ctx's device)
+static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, std::string& err) {
     // ---- scan rank (gid): objects in YAML order, triangles in file order (scene.rs:38, intersections.rs:148)
     struct Key { int32_t obj, tri; uint32_t kind, idx; };
     std::vector<Key> keys;
@@ -283,17 +338,22 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
     Bvh bvh;
     if (ctx->bvh_builder == 1) {
         std::string berr;
-        if (build_bvh_gpu(bvh_boxes, bvh, ctx->own_stream, berr)) return fail(ctx, "GPU BVH build failed: %s", berr.c_str());
+        DeviceGuard g(ctx->device);
+        if (build_bvh_gpu(bvh_boxes, bvh, ctx->own_stream, berr)) { err = "GPU BVH build failed: " + berr; return 1; }
     } else {
         build_bvh(bvh_boxes, bvh);
     }
     const uint32_t n_leaf_prims = (uint32_t)bvh_src.size();
 
     // ---- records: BVH primitives in leaf order, then the big spheres
-    std::vector<float4> prims((size_t)n_prims * 3);
-    std::vector<int4> meta(n_prims);
-    std::vector<float4> smeta((size_t)n_prims * 4);   // 64-byte shading records: (normal, material | flags) + a copy of the primitive record
-    std::vector<float> uvs;
+    std::vector<float4>& prims = f.prims;
+    std::vector<int4>& meta = f.meta;
+    std::vector<float4>& smeta = f.smeta;   // 64-byte shading records: (normal, material | flags) + a copy of the primitive record
+    std::vector<float>& uvs = f.uvs;
+    prims.assign((size_t)n_prims * 3, make_float4(0.f, 0.f, 0.f, 0.f));
+    meta.assign(n_prims, make_int4(0, 0, 0, 0));
+    smeta.assign((size_t)n_prims * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    uvs.clear();
     for (uint32_t k = 0; k < n_prims; ++k) {
         uint32_t src = k < n_leaf_prims ? bvh_src[bvh.order[k]] : big_src[k - n_leaf_prims];
         float4* r = &prims[(size_t)k * 3];
@@ -336,11 +396,14 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         }
         for (int q = 0; q < 3; ++q) smeta[(size_t)k * 4 + 1 + q] = r[q];
     }
-    std::vector<float4> nodes(bvh.nodes.size() * 4);
+    std::vector<float4>& nodes = f.nodes;
+    nodes.assign(bvh.nodes.size() * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     if (!bvh.nodes.empty()) std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(GpuNode));
 
-    std::vector<float4> planes((size_t)d->n_planes * 2);
-    std::vector<int32_t> plane_obj(d->n_planes);
+    std::vector<float4>& planes = f.planes;
+    std::vector<int32_t>& plane_obj = f.plane_obj;
+    planes.assign((size_t)d->n_planes * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    plane_obj.assign(d->n_planes, 0);
     for (uint32_t i = 0; i < d->n_planes; ++i) {
         float gf, mf;
         uint32_t gw = gid_plane[i];
@@ -350,64 +413,135 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
         planes[2 * i + 1] = make_float4((float)d->plane_normal[3 * i], (float)d->plane_normal[3 * i + 1], (float)d->plane_normal[3 * i + 2], mf);
         plane_obj[i] = d->plane_object[i];
     }
-    std::vector<float4> mats((size_t)d->n_materials * 2);
+    std::vector<float4>& mats = f.mats;
+    mats.assign((size_t)d->n_materials * 2, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         mats[2 * i] = make_float4((float)d->mat_rgb[3 * i], (float)d->mat_rgb[3 * i + 1], (float)d->mat_rgb[3 * i + 2], (float)d->mat_param[i]);
         int32_t w[4] = {d->mat_type[i], d->mat_texture ? d->mat_texture[i] : -1, 0, 0};
         std::memcpy(&mats[2 * i + 1], w, 16);
     }
-    std::vector<int4> textures(d->n_textures);
-    std::vector<uchar4> texels;
+    std::vector<int4>& textures = f.textures;
+    std::vector<uchar4>& texels = f.texels;
+    textures.assign(d->n_textures, make_int4(0, 0, 0, 0));
+    texels.clear();
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         size_t n = (size_t)d->tex_width[i] * d->tex_height[i];
-        if (n == 0 || n > (1ull << 30)) return fail(ctx, "texture %u has an invalid size", i);
+        if (n == 0 || n > (1ull << 30) || !d->tex_rgb8[i]) { err = "texture " + std::to_string(i) + " has an invalid size or no pixels"; return 1; }
         textures[i] = make_int4((int)texels.size(), (int)d->tex_width[i], (int)d->tex_height[i], 0);
         const uint8_t* px = d->tex_rgb8[i];
         for (size_t k = 0; k < n; ++k) texels.push_back(make_uchar4(px[3 * k], px[3 * k + 1], px[3 * k + 2], 255));
     }
-    std::vector<float4> lights(d->n_lights);
+    std::vector<float4>& lights = f.lights;
+    lights.assign(d->n_lights, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < d->n_lights; ++i)
         lights[i] = make_float4((float)d->light_point[3 * i], (float)d->light_point[3 * i + 1], (float)d->light_point[3 * i + 2], 0.f);
 
+    f.n_prims = n_prims;
+    f.n_leaf_prims = n_leaf_prims;
+    f.n_nodes = (uint32_t)bvh.nodes.size();
+    f.n_planes = d->n_planes;
+    f.n_lights = d->n_lights;
+    for (int k = 0; k < 3; ++k) {
+        f.bg[k] = (float)d->background[k];
+        f.eye[k] = (float)d->cam_eye[k];
+        f.lle[k] = d->cam_lower_left[k] - d->cam_eye[k];
+        f.hz[k] = d->cam_horizontal[k];
+        f.vt[k] = d->cam_vertical[k];
+    }
+    f.width = d->width; f.height = d->height;
+    f.stack_depth = std::max<uint32_t>(bvh.max_stack, 2);
+    f.bvh_depth = bvh.max_depth;
+    f.bvh_build_ms = bvh.build_ms;
+    return 0;
+}
+
+// copies a flattened scene to the context's GPU
+static int upload_flat(rt_context* ctx, const FlatScene& f) {
+    DeviceGuard g(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    free_scene(ctx);
     DevScene sc{};
-    if (upload(ctx, nodes, &sc.nodes) || upload(ctx, prims, &sc.prims) || upload(ctx, meta, &sc.meta) || upload(ctx, smeta, &sc.smeta) || upload(ctx, uvs, &sc.uvs) ||
-        upload(ctx, planes, &sc.planes) || upload(ctx, plane_obj, &sc.plane_object) || upload(ctx, mats, &sc.materials) ||
-        upload(ctx, textures, &sc.textures) || upload(ctx, texels, &sc.texels) || upload(ctx, lights, &sc.lights)) {
+    if (upload(ctx, f.nodes, &sc.nodes) || upload(ctx, f.prims, &sc.prims) || upload(ctx, f.meta, &sc.meta) || upload(ctx, f.smeta, &sc.smeta) ||
+        upload(ctx, f.uvs, &sc.uvs) || upload(ctx, f.planes, &sc.planes) || upload(ctx, f.plane_obj, &sc.plane_object) ||
+        upload(ctx, f.mats, &sc.materials) || upload(ctx, f.textures, &sc.textures) || upload(ctx, f.texels, &sc.texels) ||
+        upload(ctx, f.lights, &sc.lights)) {
         free_scene(ctx);
         return 1;
     }
-    sc.n_prims = n_prims;
-    sc.n_leaf_prims = n_leaf_prims;
-    sc.n_nodes = (uint32_t)bvh.nodes.size();
-    sc.n_planes = d->n_planes;
-    sc.n_lights = d->n_lights;
-    for (int k = 0; k < 3; ++k) {
-        sc.bg[k] = (float)d->background[k];
-        sc.eye[k] = (float)d->cam_eye[k];
-        sc.lle[k] = d->cam_lower_left[k] - d->cam_eye[k];
-        sc.hz[k] = d->cam_horizontal[k];
-        sc.vt[k] = d->cam_vertical[k];
-    }
-    sc.width = d->width; sc.height = d->height;
-    sc.stack_depth = std::max<uint32_t>(bvh.max_stack, 2);
+    sc.n_prims = f.n_prims;
+    sc.n_leaf_prims = f.n_leaf_prims;
+    sc.n_nodes = f.n_nodes;
+    sc.n_planes = f.n_planes;
+    sc.n_lights = f.n_lights;
+    for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.lle[k] = f.lle[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
+    sc.width = f.width; sc.height = f.height;
+    sc.stack_depth = f.stack_depth;
     sc.spill_levels = sc.stack_depth > LDS_STACK ? sc.stack_depth - LDS_STACK : 0;
     {   // overflow area of the LDS traversal stacks: one slice per persistent closest-hit wave
         const size_t waves = (size_t)ctx->cfg.n_cu * HIT_BLOCKS_PER_CU * 4;
         const size_t bytes = std::max<size_t>(16, waves * 64 * sc.spill_levels * sizeof(uint32_t));
         void* sp = nullptr;
-        HIP_TRY(ctx, hipMalloc(&sp, bytes));
+        hipError_t e = hipMalloc(&sp, bytes);
+        if (e != hipSuccess) { free_scene(ctx); return fail(ctx, "hipMalloc of the stack overflow area failed: %s", hipGetErrorString(e)); }
         ctx->scene_allocs.push_back(sp);
         sc.spill = reinterpret_cast<uint32_t*>(sp);
     }
     ctx->sc = sc;
-    ctx->bvh_nodes = sc.n_nodes; ctx->bvh_depth = bvh.max_depth; ctx->bvh_prims = n_prims; ctx->bvh_build_ms = bvh.build_ms;
+    ctx->bvh_nodes = sc.n_nodes; ctx->bvh_depth = f.bvh_depth; ctx->bvh_prims = f.n_prims; ctx->bvh_build_ms = f.bvh_build_ms;
     ctx->have_scene = true;
     return 0;
 }
 
+extern "C" int rt_scene_upload_devices(rt_context* const* ctxs, uint32_t n, const rt_scene_desc* d) {
+    if (!ctxs || n == 0 || !ctxs[0]) return fail(nullptr, "ctxs is NULL or empty");
+    for (uint32_t k = 0; k < n; ++k) if (!ctxs[k]) return fail(ctxs[0], "context %u is NULL", k);
+    if (!d) return fail(ctxs[0], "scene is NULL");
+    try {
+        std::string err;
+        if (validate_desc(d, err)) { for (uint32_t k = 1; k < n; ++k) ctxs[k]->error = err; return fail(ctxs[0], "%s", err.c_str()); }
+        FlatScene f;
+        if (flatten_scene(ctxs[0], d, f, err)) return fail(ctxs[0], "%s", err.c_str());
+        for (uint32_t k = 0; k < n; ++k)
+            if (upload_flat(ctxs[k], f)) { if (k) fail(ctxs[0], "context %u: %s", k, ctxs[k]->error.c_str()); return 1; }
+        return 0;
+    } catch (const std::exception& e) {   // bad_alloc / length_error of the host-side staging: no exception crosses the ABI
+        return fail(ctxs[0], "scene upload failed: %s", e.what());
+    }
+}
+
+extern "C" int rt_scene_upload(rt_context* ctx, const rt_scene_desc* d) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    rt_context* one[1] = {ctx};
+    return rt_scene_upload_devices(one, 1, d);
+}
+
+extern "C" {
+
+// Wavefront state of one pass: the context's grown-on-demand buffers, or carved out of the static scratch array.
+struct WaveState {
+    RayQueue q[2];
+    float2* hits;
+    float4* radiance;
+    uint32_t* ctl;
+    uint32_t capacity;   // rays per queue
+};
+
+// rays a queue must hold per path of a pass: on the last bounce a firing path spawns one shadow ray per
+// light (raytrace.rs:78-85)
+static inline uint32_t rays_per_path(const DevScene& sc) { return std::max<uint32_t>(1u, sc.n_lights); }
+
+static inline size_t align256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+// bytes of static scratch a pass of `paths` paths needs (rtamd.h: RT_NOALLOC_SCRATCH_BYTES)
+static size_t noalloc_bytes(uint32_t paths, uint32_t per_path) {
+    const size_t cap = (size_t)paths * per_path;
+    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + align256(cap * sizeof(float2)) + align256((size_t)paths * sizeof(float4));
+}
+
 // One call = raytrace.rs:126-143 for a sample range and a tile set (see rtamd.h).
+// use_scratch: the no-alloc entry point -- one pass, state in the static scratch array, nothing allocated.
 static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, float* accum_dev, hipStream_t st, bool hits_only,
-                                  PassParams* pp_out) {
+                                  PassParams* pp_out, WaveState* ws_out, bool use_scratch = false) {
     uint32_t sb, se, tcount;
     if (check_params(ctx, p, &sb, &se, &tcount)) return 1;
     if (!accum_dev && !hits_only) return fail(ctx, "accum_dev is NULL");
@@ -416,32 +550,71 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
     const uint32_t n_local = p->tile_index < n_tiles ? (uint32_t)((n_tiles - p->tile_index + tcount - 1) / tcount) : 0;
     if (n_local == 0 || sb == se) return 0;
-    uint32_t max_paths = p->max_paths_per_pass ? p->max_paths_per_pass : (1u << 27);   // few, large launches: 16 Mi-path passes were 15 % slower
-    max_paths = std::max<uint32_t>(64, max_paths & ~63u);
+    const uint32_t per_path = rays_per_path(sc);
     const uint32_t gens = sc.n_lights ? (p->max_shadow_generations ? p->max_shadow_generations : 16u) : 0u;
     if (p->depth + gens + 1 > (uint32_t)CTL_MAX_IT) return fail(ctx, "depth + shadow generations exceeds %d", CTL_MAX_IT - 1);
-
-    // tiles per pass / samples per pass.  With the default pass size a device that cannot hold the
-    // queues (128 B per path) gets smaller passes instead of an error.
-    uint32_t tiles_pass, samples_pass;
-    for (;;) {
-        tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
-        samples_pass = std::max<uint32_t>(1, std::min<uint32_t>(se - sb, max_paths / (tiles_pass * 64)));
-        const uint32_t pass_paths = tiles_pass * 64 * samples_pass;
-        // a firing path spawns one shadow ray per light (raytrace.rs:78-85)
-        const uint64_t cap64 = (uint64_t)pass_paths * std::max<uint32_t>(1, std::min<uint32_t>(sc.n_lights, 4));
-        if (cap64 > 0xFFFFFF00ull) {
-            if (!p->max_paths_per_pass && max_paths > (1u << 20)) { max_paths >>= 1; continue; }
-            return fail(ctx, "pass too large");
-        }
-        if (ensure_state(ctx, pass_paths, (uint32_t)cap64) == 0) break;
-        free_state(ctx);
-        (void)hipGetLastError();
-        if (p->max_paths_per_pass || max_paths <= (1u << 20)) return 1;
-        max_paths >>= 1;
-    }
-    const uint32_t capacity = ctx->capacity;
     const bool counters = (p->flags & RT_FLAG_COUNTERS) != 0, timing = (p->flags & RT_FLAG_TIMING) != 0;
+
+    uint32_t tiles_pass, samples_pass;
+    WaveState ws{};
+    if (use_scratch) {
+        // no allocation of any kind on this path: no hipMalloc, no event creation, no growing vectors
+        if (timing) return fail(ctx, "RT_FLAG_TIMING is not available without allocation (it creates events)");
+        if (!ctx->scratch_ptr) return fail(ctx, "no scratch array on device %d", ctx->device);
+        const uint64_t paths64 = (uint64_t)n_local * 64u * (se - sb);
+        if (p->max_paths_per_pass && p->max_paths_per_pass < paths64)
+            return fail(ctx, "the call has %llu paths but max_paths_per_pass = %u: the no-alloc entry point renders ONE pass", (unsigned long long)paths64,
+                        p->max_paths_per_pass);
+        if (paths64 > 0xFFFFFFFFull / per_path || noalloc_bytes((uint32_t)paths64, per_path) > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+            return fail(ctx, "the call has %llu paths (tiles x 64 x samples) with %u queue slots each: more than the %u MiB static scratch holds "
+                             "(%llu bytes needed); split the samples or the tiles over several calls",
+                        (unsigned long long)paths64, per_path, (unsigned)(RT_NOALLOC_SCRATCH_BYTES >> 20),
+                        (unsigned long long)(paths64 > 0xFFFFFFFFull / per_path ? ~0ull : noalloc_bytes((uint32_t)paths64, per_path)));
+        tiles_pass = n_local; samples_pass = se - sb;
+        const uint32_t paths = (uint32_t)paths64;
+        const size_t cap = (size_t)paths * per_path;
+        unsigned char* base = static_cast<unsigned char*>(ctx->scratch_ptr);   // the runtime's address of `scratch` on this GPU, never the symbol
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { unsigned char* r = base + off; off += align256(bytes); return r; };
+        ws.ctl = reinterpret_cast<uint32_t*>(carve(CTL_WORDS * sizeof(uint32_t)));
+        for (int k = 0; k < 2; ++k) {
+            ws.q[k].a = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
+            ws.q[k].b = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
+            ws.q[k].c = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
+        }
+        ws.hits = reinterpret_cast<float2*>(carve(cap * sizeof(float2)));
+        ws.radiance = reinterpret_cast<float4*>(carve((size_t)paths * sizeof(float4)));
+        ws.capacity = (uint32_t)cap;
+    } else {
+        // few, large launches: 16 Mi-path passes were 15 % slower than one of 128 Mi.  Scenes with many lights need
+        // one queue slot per light and path, so their default pass is smaller.
+        uint32_t max_paths = p->max_paths_per_pass ? p->max_paths_per_pass : std::max<uint32_t>(1u << 20, (1u << 27) / std::max(1u, per_path / 4u));
+        max_paths = std::max<uint32_t>(64, max_paths & ~63u);
+        // tiles per pass / samples per pass.  With the default pass size a device that cannot hold the
+        // queues (>= 120 B per path) gets smaller passes instead of an error.
+        uint64_t cap64;
+        for (;;) {
+            tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
+            samples_pass = std::max<uint32_t>(1, std::min<uint32_t>(se - sb, max_paths / (tiles_pass * 64)));
+            const uint32_t pass_paths = tiles_pass * 64 * samples_pass;
+            cap64 = (uint64_t)pass_paths * per_path;
+            if (cap64 > 0xFFFFFF00ull) {
+                if (max_paths > 64u && (!p->max_paths_per_pass || per_path > 1u)) { max_paths = std::max(64u, (max_paths >> 1) & ~63u); continue; }
+                return fail(ctx, "pass too large");
+            }
+            if (ensure_state(ctx, pass_paths, (uint32_t)cap64) == 0) break;
+            free_state(ctx);
+            (void)hipGetLastError();
+            if (p->max_paths_per_pass || max_paths <= (1u << 20)) return 1;
+            max_paths >>= 1;
+        }
+        ws.q[0] = ctx->q[0]; ws.q[1] = ctx->q[1]; ws.hits = ctx->hits; ws.radiance = ctx->radiance; ws.ctl = ctx->ctl;
+        // the capacity of THIS call, not of the (possibly larger) buffers an earlier call left behind: whether rays
+        // are dropped must not depend on the context's history
+        ws.capacity = (uint32_t)cap64;
+    }
+    const uint32_t capacity = ws.capacity;
+    if (ws_out) *ws_out = ws;
 
     for (uint32_t lt0 = 0; lt0 < n_local; lt0 += tiles_pass) {
         const uint32_t nt = std::min(tiles_pass, n_local - lt0);
@@ -455,8 +628,8 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             pp.off_x = (float)p->sample_offset[0]; pp.off_y = (float)p->sample_offset[1];
             pp.seed_lo = (uint32_t)p->seed; pp.seed_hi = (uint32_t)(p->seed >> 32);
             if (pp_out) *pp_out = pp;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
-            launch_raygen(ctx->cfg, sc, pp, ctx->q[0], ctx->radiance, ctx->ctl, capacity, st);
+            HIP_TRY(ctx, hipMemsetAsync(ws.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
+            launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
             {   // primary rays = pixels of the pass's tiles that lie inside the image
                 uint64_t px = 0;
                 for (uint32_t lt = lt0; lt < lt0 + nt; ++lt) {
@@ -471,7 +644,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             const uint32_t depth = hits_only ? 1u : p->depth;
             const uint32_t iters = depth ? depth + gens : 0u;          // raytrace.rs:52-54: depth 0 traces nothing
             for (uint32_t it = 0; it < iters; ++it) {
-                RayQueue qi = ctx->q[it & 1], qo = ctx->q[(it + 1) & 1];
+                RayQueue qi = ws.q[it & 1], qo = ws.q[(it + 1) & 1];
                 const uint32_t max_rays = it < depth ? pp.n_paths : capacity;
                 if (timing) {
                     if (ctx->events_used == ctx->events.size()) {
@@ -482,17 +655,19 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                     }
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].first, st));
                 }
-                launch_closest_hit(ctx->cfg, sc, qi, ctx->hits, ctx->ctl, (int)it, capacity, max_rays, counters, st);
+                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, st);
                 if (timing) {
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].second, st));
                     ctx->events_used++;
                 }
                 if (hits_only) break;
-                const int last = it + 1 >= depth;
-                launch_shade(ctx->cfg, sc, qi, ctx->hits, qo, ctx->radiance, ctx->ctl, (int)it, last, capacity, max_rays, st);
+                // 0: a bounce before the last; 1: last bounce or a shadow generation, shadow rays go to the next
+                // generation; 2: the last generation this call runs (max_shadow_generations): nothing is emitted
+                const int last = it + 1 < depth ? 0 : (it + 1 < iters ? 1 : 2);
+                launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, st);
             }
-            if (!hits_only) launch_accumulate(sc, pp, ctx->radiance, accum_dev, st);
-            launch_stats(ctx->ctl, ctx->stats_dev, capacity, st);
+            if (!hits_only) launch_accumulate(sc, pp, ws.radiance, accum_dev, st);
+            launch_stats(ws.ctl, ctx->stats_dev, capacity, st);
             HIP_TRY(ctx, hipGetLastError());
             if (hits_only) return 0;   // single pass by construction
         }
@@ -503,7 +678,17 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
 int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, float* accum_dev, void* stream) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     DeviceGuard g(ctx->device);
-    return render_accumulate_impl(ctx, params, accum_dev, (hipStream_t)stream, false, nullptr);
+    try {
+        return render_accumulate_impl(ctx, params, accum_dev, (hipStream_t)stream, false, nullptr, nullptr);
+    } catch (const std::exception& e) {
+        return fail(ctx, "render failed: %s", e.what());
+    }
+}
+
+int rt_render_accumulate_noalloc(rt_context* ctx, const rt_render_params* params, float* accum_dev, void* stream) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    return render_accumulate_impl(ctx, params, accum_dev, (hipStream_t)stream, false, nullptr, nullptr, true);
 }
 
 int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t spp_total, uint8_t* rgb8_dev, float* color_dev, void* stream) {
@@ -512,10 +697,24 @@ int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t spp_total, uint
     if (!accum_dev) return fail(ctx, "accum_dev is NULL");
     if (spp_total == 0) return fail(ctx, "spp_total must be non-zero");
     DeviceGuard g(ctx->device);
-    const uint32_t n = ctx->sc.width * ctx->sc.height * 3u;
+    const size_t n = (size_t)ctx->sc.width * ctx->sc.height * 3u;
     launch_resolve(accum_dev, n, 1.0f / (float)spp_total, rgb8_dev, color_dev, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
+}
+
+// rays dropped so far because a queue was full (only the branching shadow-ray process of scenes with four
+// or more lights can do that, raytrace.rs:78-85); they make an image wrong, so the synchronous calls report them
+static unsigned long long dropped_rays(rt_context* ctx) {
+    unsigned long long v = 0;
+    if (ctx->stats_dev) (void)hipMemcpy(&v, ctx->stats_dev + CTL_MAX_IT, sizeof(v), hipMemcpyDeviceToHost);
+    return v;
+}
+static int report_dropped(rt_context* ctx, unsigned long long lost) {
+    return fail(ctx, "%llu rays were dropped: the shadow-ray queue overflowed.  The scene has %u lights: from 4 lights on every shadow ray spawns "
+                     "more than one successor on average (raytrace.rs:78-85) and the reference itself recurses without bound; "
+                     "set max_shadow_generations to cut the process off earlier",
+                lost, ctx->sc.n_lights);
 }
 
 int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accum_host, uint8_t* rgb8_host) {
@@ -529,39 +728,33 @@ int rt_render_image(rt_context* ctx, const rt_render_params* params, float* accu
     HIP_TRY(ctx, hipMalloc((void**)&accum, n * sizeof(float)));
     int rc = 0;
     hipStream_t st = ctx->own_stream;
-    // rays dropped because a queue was full (only the branching shadow-ray process of scenes with
-    // several lights can do that, raytrace.rs:78-85) make the image wrong: this call reports them
-    auto dropped = [&]() -> unsigned long long {
-        unsigned long long v = 0;
-        if (ctx->stats_dev) (void)hipMemcpy(&v, ctx->stats_dev + CTL_MAX_IT, sizeof(v), hipMemcpyDeviceToHost);
-        return v;
-    };
-    const unsigned long long dropped_before = dropped();
-    do {
-        if (hipMemsetAsync(accum, 0, n * sizeof(float), st) != hipSuccess) { rc = fail(ctx, "hipMemsetAsync failed"); break; }
-        if ((rc = render_accumulate_impl(ctx, params, accum, st, false, nullptr))) break;
-        if (rgb8_host) {
-            if (hipMalloc((void**)&rgb8, n) != hipSuccess) { rc = fail(ctx, "hipMalloc failed"); break; }
-            // raytrace.rs:144: divide by the number of samples of the pixel (here: of the range traced)
-            if ((rc = rt_resolve(ctx, accum, se - sb ? se - sb : 1, rgb8, nullptr, st))) break;
-        }
-        hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { rc = fail(ctx, "render failed: %s", hipGetErrorString(e)); break; }
-        if (accum_host && hipMemcpy(accum_host, accum, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
-        if (rgb8_host && hipMemcpy(rgb8_host, rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
-        const unsigned long long lost = dropped() - dropped_before;
-        if (lost) rc = fail(ctx, "%llu rays were dropped: the shadow-ray queue overflowed (%u lights; lower max_shadow_generations or max_paths_per_pass)",
-                            lost, ctx->sc.n_lights);
-    } while (0);
+    const unsigned long long dropped_before = dropped_rays(ctx);
+    try {
+        do {
+            if (hipMemsetAsync(accum, 0, n * sizeof(float), st) != hipSuccess) { rc = fail(ctx, "hipMemsetAsync failed"); break; }
+            if ((rc = render_accumulate_impl(ctx, params, accum, st, false, nullptr, nullptr))) break;
+            if (rgb8_host) {
+                if (hipMalloc((void**)&rgb8, n) != hipSuccess) { rc = fail(ctx, "hipMalloc failed"); break; }
+                // raytrace.rs:144: divide by the number of samples of the pixel (here: of the range traced)
+                if ((rc = rt_resolve(ctx, accum, se - sb ? se - sb : 1, rgb8, nullptr, st))) break;
+            }
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rc = fail(ctx, "render failed: %s", hipGetErrorString(e)); break; }
+            if (accum_host && hipMemcpy(accum_host, accum, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
+            if (rgb8_host && hipMemcpy(rgb8_host, rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
+            const unsigned long long lost = dropped_rays(ctx) - dropped_before;
+            if (lost) rc = report_dropped(ctx, lost);
+        } while (0);
+    } catch (const std::exception& e) {
+        rc = fail(ctx, "render failed: %s", e.what());
+    }
     (void)hipFree(accum);
     (void)hipFree(rgb8);
     return rc;
 }
 
-int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, int32_t* triangle_id, float* t, float* normal_xyz) {
-    if (!ctx) return fail(nullptr, "ctx is NULL");
-    if (!ctx->have_scene) return fail(ctx, "no scene uploaded");
-    if (!object_id || !triangle_id || !t || !normal_xyz) return fail(ctx, "output pointer is NULL");
+// shared by rt_primary_hits and rt_primary_rays: one uniform-grid sample per pixel, closest hit only
+static int primary_pass(rt_context* ctx, double dx, double dy, int32_t* object_id, int32_t* triangle_id, float* t, float* normal_xyz, float* dir_xyz) {
     DeviceGuard g(ctx->device);
     const size_t npx = (size_t)ctx->sc.width * ctx->sc.height;
     const uint32_t tiles = ((ctx->sc.width + 7) / 8) * ((ctx->sc.height + 7) / 8);
@@ -570,22 +763,161 @@ int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, i
     p.max_paths_per_pass = tiles * 64;   // one pass over every tile
     p.sample_offset[0] = dx; p.sample_offset[1] = dy;
     int32_t *d_obj = nullptr, *d_tri = nullptr;
-    float *d_t = nullptr, *d_n = nullptr;
+    float *d_t = nullptr, *d_n = nullptr, *d_d = nullptr;
     int rc = 0;
     hipStream_t st = ctx->own_stream;
-    do {
-        if (hipMalloc((void**)&d_obj, npx * 4) != hipSuccess || hipMalloc((void**)&d_tri, npx * 4) != hipSuccess ||
-            hipMalloc((void**)&d_t, npx * 4) != hipSuccess || hipMalloc((void**)&d_n, npx * 12) != hipSuccess) { rc = fail(ctx, "hipMalloc failed"); break; }
-        PassParams pp{};
-        if ((rc = render_accumulate_impl(ctx, &p, nullptr, st, true, &pp))) break;
-        launch_hit_info(ctx->sc, pp, ctx->q[0], ctx->hits, ctx->ctl, ctx->capacity, d_obj, d_tri, d_t, d_n, st);
-        hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { rc = fail(ctx, "primary hits failed: %s", hipGetErrorString(e)); break; }
-        if (hipMemcpy(object_id, d_obj, npx * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(triangle_id, d_tri, npx * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(t, d_t, npx * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(normal_xyz, d_n, npx * 12, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
-    } while (0);
-    (void)hipFree(d_obj); (void)hipFree(d_tri); (void)hipFree(d_t); (void)hipFree(d_n);
+    try {
+        do {
+            if (object_id && (hipMalloc((void**)&d_obj, npx * 4) != hipSuccess || hipMalloc((void**)&d_tri, npx * 4) != hipSuccess ||
+                              hipMalloc((void**)&d_t, npx * 4) != hipSuccess || hipMalloc((void**)&d_n, npx * 12) != hipSuccess)) { rc = fail(ctx, "hipMalloc failed"); break; }
+            if (dir_xyz && hipMalloc((void**)&d_d, npx * 12) != hipSuccess) { rc = fail(ctx, "hipMalloc failed"); break; }
+            PassParams pp{};
+            WaveState ws{};
+            if ((rc = render_accumulate_impl(ctx, &p, nullptr, st, true, &pp, &ws))) break;
+            launch_hit_info(ctx->sc, pp, ws.q[0], ws.hits, ws.ctl, ws.capacity, d_obj, d_tri, d_t, d_n, d_d, st);
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rc = fail(ctx, "primary hits failed: %s", hipGetErrorString(e)); break; }
+            if (object_id && (hipMemcpy(object_id, d_obj, npx * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(triangle_id, d_tri, npx * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(t, d_t, npx * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(normal_xyz, d_n, npx * 12, hipMemcpyDeviceToHost) != hipSuccess)) { rc = fail(ctx, "copy failed"); break; }
+            if (dir_xyz && hipMemcpy(dir_xyz, d_d, npx * 12, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, "copy failed"); break; }
+        } while (0);
+    } catch (const std::exception& e) {
+        rc = fail(ctx, "primary hits failed: %s", e.what());
+    }
+    (void)hipFree(d_obj); (void)hipFree(d_tri); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_d);
     return rc;
+}
+
+int rt_primary_hits(rt_context* ctx, double dx, double dy, int32_t* object_id, int32_t* triangle_id, float* t, float* normal_xyz) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, "no scene uploaded");
+    if (!object_id || !triangle_id || !t || !normal_xyz) return fail(ctx, "output pointer is NULL");
+    return primary_pass(ctx, dx, dy, object_id, triangle_id, t, normal_xyz, nullptr);
+}
+
+int rt_primary_rays(rt_context* ctx, double dx, double dy, float origin_xyz[3], float* dir_xyz) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, "no scene uploaded");
+    if (!origin_xyz || !dir_xyz) return fail(ctx, "output pointer is NULL");
+    for (int k = 0; k < 3; ++k) origin_xyz[k] = ctx->sc.eye[k];
+    return primary_pass(ctx, dx, dy, nullptr, nullptr, nullptr, nullptr, dir_xyz);
+}
+
+// ---------------------------------------------------------------- multi-GPU exchange step inside the library
+static int ensure_values(rt_context* ctx, float** buf, size_t* have, size_t want) {
+    if (*have >= want) return 0;
+    (void)hipFree(*buf);
+    *buf = nullptr; *have = 0;
+    HIP_TRY(ctx, hipMalloc((void**)buf, want * sizeof(float)));
+    *have = want;
+    return 0;
+}
+
+int rt_accum_reduce(rt_context* dst, float* dst_accum_dev, rt_context* const* src, const float* const* src_accum_dev, uint32_t n_src, void* stream) {
+    if (!dst) return fail(nullptr, "dst is NULL");
+    if (!dst->have_scene) return fail(dst, "no scene uploaded");
+    if (!dst_accum_dev || (n_src && (!src || !src_accum_dev))) return fail(dst, "NULL argument");
+    DeviceGuard g(dst->device);
+    const size_t n = (size_t)dst->sc.width * dst->sc.height * 3;
+    hipStream_t st = (hipStream_t)stream;
+    for (uint32_t k = 0; k < n_src; ++k) {
+        if (!src[k] || !src_accum_dev[k]) return fail(dst, "source %u is NULL", k);
+        if (!src[k]->have_scene || src[k]->sc.width != dst->sc.width || src[k]->sc.height != dst->sc.height)
+            return fail(dst, "source %u renders a different frame size", k);
+        const float* from = src_accum_dev[k];
+        if (src[k]->device != dst->device) {
+            // partial frame of another GPU: one peer copy over xGMI into the landing buffer, then the add
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, dst->device, src[k]->device);
+            if (can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(src[k]->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is fine; without peer access the copy is staged by the runtime
+            }
+            if (ensure_values(dst, &dst->staging, &dst->staging_values, n)) return 1;
+            HIP_TRY(dst, hipMemcpyPeerAsync(dst->staging, dst->device, from, src[k]->device, n * sizeof(float), st));
+            from = dst->staging;
+        }
+        launch_accum_add(dst->cfg, dst_accum_dev, from, n, st);   // stream order also protects the landing buffer's reuse
+        HIP_TRY(dst, hipGetLastError());
+    }
+    return 0;
+}
+
+int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render_params* params, int split_tiles, float* accum_host, uint8_t* rgb8_host) {
+    if (!ctxs || n == 0 || !ctxs[0]) return fail(nullptr, "ctxs is NULL or empty");
+    rt_context* root = ctxs[0];
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!ctxs[k]) return fail(root, "context %u is NULL", k);
+        for (uint32_t j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) return fail(root, "context %u is listed twice", k);
+    }
+    uint32_t sb, se, tcount;
+    if (check_params(root, params, &sb, &se, &tcount)) return 1;
+    const size_t nval = (size_t)root->sc.width * root->sc.height * 3;
+    for (uint32_t k = 1; k < n; ++k)
+        if (!ctxs[k]->have_scene || ctxs[k]->sc.width != root->sc.width || ctxs[k]->sc.height != root->sc.height)
+            return fail(root, "context %u holds a different scene (use rt_scene_upload_devices)", k);
+    try {
+        // one host thread per GPU, as the contexts are single-threaded objects bound to one device each
+        std::vector<int> rcs(n, 0);
+        std::vector<unsigned long long> before(n, 0);
+        std::vector<std::thread> threads;
+        for (uint32_t k = 0; k < n; ++k)
+            threads.emplace_back([&, k]() {
+                rt_context* c = ctxs[k];
+                DeviceGuard g(c->device);
+                rt_render_params p = *params;
+                bool work = true;
+                if (split_tiles) {
+                    // tiles t with t % tcount == tile_index, dealt round-robin once more between the n devices
+                    p.tile_count = tcount * n; p.tile_index = params->tile_index + k * tcount;
+                } else {
+                    // contiguous sample ranges, the first (count % n) devices take one more (same RNG keys as one device)
+                    const uint32_t cnt = se - sb, base = cnt / n, extra = cnt % n;
+                    p.sample_begin = sb + k * base + std::min(k, extra);
+                    p.sample_end = p.sample_begin + base + (k < extra ? 1u : 0u);
+                    work = p.sample_end > p.sample_begin;     // more devices than samples: this one only clears its frame
+                }
+                before[k] = dropped_rays(c);
+                if (ensure_values(c, &c->own_accum, &c->own_accum_values, nval)) { rcs[k] = 1; return; }
+                if (hipMemsetAsync(c->own_accum, 0, nval * sizeof(float), c->own_stream) != hipSuccess) { rcs[k] = fail(c, "hipMemsetAsync failed"); return; }
+                if (work) {
+                    try { rcs[k] = render_accumulate_impl(c, &p, c->own_accum, c->own_stream, false, nullptr, nullptr); }
+                    catch (const std::exception& e) { rcs[k] = fail(c, "render failed: %s", e.what()); }
+                }
+                if (!rcs[k]) {
+                    hipError_t e = hipStreamSynchronize(c->own_stream);
+                    if (e != hipSuccess) rcs[k] = fail(c, "render failed: %s", hipGetErrorString(e));
+                }
+            });
+        for (auto& t : threads) t.join();
+        for (uint32_t k = 0; k < n; ++k)
+            if (rcs[k]) return k ? fail(root, "device %d: %s", ctxs[k]->device, ctxs[k]->error.c_str()) : 1;
+        // exchange: the partial frames are summed on the first context's GPU (peer copies + adds), resolved there
+        // (raytrace.rs:144-150, image.rs:37-43) and copied to the host once
+        DeviceGuard g(root->device);
+        std::vector<const float*> parts;
+        for (uint32_t k = 1; k < n; ++k) parts.push_back(ctxs[k]->own_accum);
+        if (n > 1 && rt_accum_reduce(root, root->own_accum, ctxs + 1, parts.data(), n - 1, root->own_stream)) return 1;
+        uint8_t* rgb8 = nullptr;
+        int rc = 0;
+        do {
+            if (rgb8_host) {
+                if (hipMalloc((void**)&rgb8, nval) != hipSuccess) { rc = fail(root, "hipMalloc failed"); break; }
+                if ((rc = rt_resolve(root, root->own_accum, se - sb ? se - sb : 1, rgb8, nullptr, root->own_stream))) break;
+            }
+            hipError_t e = hipStreamSynchronize(root->own_stream);
+            if (e != hipSuccess) { rc = fail(root, "exchange failed: %s", hipGetErrorString(e)); break; }
+            if (accum_host && hipMemcpy(accum_host, root->own_accum, nval * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(root, "copy failed"); break; }
+            if (rgb8_host && hipMemcpy(rgb8_host, rgb8, nval, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(root, "copy failed"); break; }
+            unsigned long long lost = 0;
+            for (uint32_t k = 0; k < n; ++k) { DeviceGuard gk(ctxs[k]->device); lost += dropped_rays(ctxs[k]) - before[k]; }
+            if (lost) rc = report_dropped(root, lost);
+        } while (0);
+        (void)hipFree(rgb8);
+        return rc;
+    } catch (const std::exception& e) {
+        return fail(root, "multi-device render failed: %s", e.what());
+    }
 }
 
 int rt_context_set_bvh_builder(rt_context* ctx, int builder) {
@@ -600,21 +932,21 @@ int rt_bvh_build_validate(rt_context* ctx, uint64_t n, const float* boxes, uint3
     if (!boxes && n) return fail(ctx, "boxes is NULL");
     if (n > 0x7FFFFFF0ull) return fail(ctx, "too many primitives");
     DeviceGuard g(ctx->device);
-    std::vector<PrimBox> pb(n);
-    for (uint64_t i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) { pb[i].mn[k] = boxes[6 * i + k]; pb[i].mx[k] = boxes[6 * i + 3 + k]; }
-    Bvh bvh;
-    if (ctx->bvh_builder == 1) {
-        std::string berr;
-        if (build_bvh_gpu(pb, bvh, ctx->own_stream, berr)) return fail(ctx, "GPU BVH build failed: %s", berr.c_str());
-    } else {
-        build_bvh(pb, bvh);
-    }
-    if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
-    if (depth) *depth = bvh.max_depth;
-    if (max_stack) *max_stack = bvh.max_stack;
-    if (build_ms) *build_ms = bvh.build_ms;
     try {
+        std::vector<PrimBox> pb(n);
+        for (uint64_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) { pb[i].mn[k] = boxes[6 * i + k]; pb[i].mx[k] = boxes[6 * i + 3 + k]; }
+        Bvh bvh;
+        if (ctx->bvh_builder == 1) {
+            std::string berr;
+            if (build_bvh_gpu(pb, bvh, ctx->own_stream, berr)) return fail(ctx, "GPU BVH build failed: %s", berr.c_str());
+        } else {
+            build_bvh(pb, bvh);
+        }
+        if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
+        if (depth) *depth = bvh.max_depth;
+        if (max_stack) *max_stack = bvh.max_stack;
+        if (build_ms) *build_ms = bvh.build_ms;
         if (n && bvh.order.size() != n) return fail(ctx, "order has %zu entries for %llu primitives", bvh.order.size(), (unsigned long long)n);
         validate_bvh(bvh, pb);
     } catch (const std::exception& e) {

@@ -887,12 +887,14 @@ int rt_host_compute_image(const char* ssaa, uint32_t depth, const char* scene_pa
     return rc;
 }
 
-// The same on several GPUs of one process: one context and one host thread per device, the samples
-// (or the 8x8 tiles) split between them like the ranks of bench.py, the partial sums added on the
-// host in device order, then the reference's resolve (raytrace.rs:144-150, image.rs:37-43).
+// The same on several GPUs of one process: one context per device; the scene is flattened and its BVH built
+// once (rt_scene_upload_devices); the samples (or the 8x8 tiles) are split between the contexts like the ranks
+// of bench.py and the partial frames are summed and resolved ON the first GPU (rt_render_image_devices: peer
+// copies + add kernel + rt_resolve, raytrace.rs:144-150 / image.rs:37-43), one copy to the host.
 int rt_host_compute_image_devices(const char* ssaa, uint32_t depth, const char* scene_path, const char* output_path, const char* base_dir,
                                   const int* device_ids, uint32_t n_devices, int split_tiles, uint64_t seed, char* err, size_t err_len) {
     rt_host_scene* hs = nullptr;
+    std::vector<rt_context*> ctxs;
     int rc = 1;
     try {
         if (!ssaa || !scene_path || !output_path || !device_ids) raise("NULL argument");
@@ -903,47 +905,22 @@ int rt_host_compute_image_devices(const char* ssaa, uint32_t depth, const char* 
         if (ssaa_parse(ssaa, &mode, &n, e)) raise("error parsing ssaa argument: %s", e.c_str());
         if (depth > 255) raise("depth must fit the reference's u8 (main.rs:15-16)");
         hs = load_scene(scene_path, base_dir ? base_dir : "").release();
-        const size_t nval = (size_t)hs->desc.width * hs->desc.height * 3;
-        const uint32_t spp = n * n;
-        std::vector<std::vector<float>> part(n_devices, std::vector<float>(nval, 0.f));
-        std::vector<std::string> errors(n_devices);
-        std::vector<std::thread> threads;
-        for (uint32_t k = 0; k < n_devices; ++k)
-            threads.emplace_back([&, k]() {
-                rt_context* ctx = nullptr;
-                if (rt_context_create(device_ids[k], &ctx)) { errors[k] = rt_last_error(nullptr); return; }
-                rt_render_params p{};
-                p.ssaa_mode = mode; p.ssaa_n = n; p.depth = depth; p.seed = seed;
-                bool work = true;
-                if (split_tiles) { p.tile_index = k; p.tile_count = n_devices; }
-                else {
-                    // contiguous sample ranges, the first spp % n_devices devices take one more
-                    const uint32_t base = spp / n_devices, extra = spp % n_devices;
-                    p.sample_begin = k * base + std::min(k, extra);
-                    p.sample_end = p.sample_begin + base + (k < extra ? 1u : 0u);
-                    work = p.sample_end > p.sample_begin;
-                }
-                if (rt_scene_upload(ctx, &hs->desc)) errors[k] = rt_last_error(ctx);
-                else if (work && rt_render_image(ctx, &p, part[k].data(), nullptr)) errors[k] = rt_last_error(ctx);
-                rt_context_destroy(ctx);
-            });
-        for (auto& t : threads) t.join();
-        for (uint32_t k = 0; k < n_devices; ++k)
-            if (!errors[k].empty()) raise("device %d: %s", device_ids[k], errors[k].c_str());
-        std::vector<uint8_t> rgb(nval);
-        const float inv = 1.0f / (float)spp;
-        for (size_t i = 0; i < nval; ++i) {
-            float sum = 0.f;
-            for (uint32_t k = 0; k < n_devices; ++k) sum += part[k][i];
-            const float c = std::fmin(std::sqrt(sum * inv), 1.0f);      // f64::min(NaN, 1.0) == 1.0
-            const float v = 255.999f * c;
-            rgb[i] = !(v == v) || v <= 0.f ? 0 : (v >= 255.f ? 255 : (uint8_t)v);
+        for (uint32_t k = 0; k < n_devices; ++k) {
+            rt_context* c = nullptr;
+            if (rt_context_create(device_ids[k], &c)) raise("device %d: %s", device_ids[k], rt_last_error(nullptr));
+            ctxs.push_back(c);
         }
-        write_png(output_path, rgb.data(), hs->desc.width, hs->desc.height);
+        if (rt_scene_upload_devices(ctxs.data(), n_devices, &hs->desc)) raise("%s", rt_last_error(ctxs[0]));
+        rt_render_params p{};
+        p.ssaa_mode = mode; p.ssaa_n = n; p.depth = depth; p.seed = seed;
+        std::vector<uint8_t> rgb((size_t)hs->desc.width * hs->desc.height * 3);
+        if (rt_render_image_devices(ctxs.data(), n_devices, &p, split_tiles, nullptr, rgb.data())) raise("%s", rt_last_error(ctxs[0]));
+        write_png(output_path, rgb.data(), hs->desc.width, hs->desc.height);   // raytrace.rs:155
         rc = 0;
     } catch (const std::exception& e) {
         set_err(err, err_len, e.what());
     }
+    for (rt_context* c : ctxs) rt_context_destroy(c);
     delete hs;
     return rc;
 }

@@ -17,9 +17,10 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st);
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st);
-void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st);
+void launch_resolve(const float* accum, size_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st);
 void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float2* hits, const uint32_t* ctl, uint32_t capacity,
-                     int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st);
+                     int32_t* obj, int32_t* tri, float* t, float* nrm, float* dir, hipStream_t st);
+void launch_accum_add(const LaunchCfg& cfg, float* dst, const float* src, size_t n, hipStream_t st);
 void launch_calib_gather(const float4* table, uint32_t n_records, uint32_t iters, uint32_t blocks, float* sink, hipStream_t st);
 void launch_stats(const uint32_t* ctl, unsigned long long* stats, uint32_t capacity, hipStream_t st);
 

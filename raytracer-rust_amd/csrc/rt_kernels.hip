@@ -218,6 +218,26 @@ __device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3
     return -1.f;
 }
 
+// Normal of a sphere hit, intersections.rs:68-69: (o + t d - c) / r.  The f32 t is good to 6e-8 relative, which
+// moves the hit point by 6e-8 t: on a sphere of radius 0.01 five units away that is 3e-5 of the normal, above
+// the 1e-5 bar.  One Newton step of the quadratic a t^2 + 2 hb t + c in f64 makes t exact to ~1e-14 for this
+// purpose; the normal is then formed in f64 and rounded once.
+__device__ __forceinline__ f3 sphere_normal(const float4 r0, const float4 r1, f3 o, f3 d, float t) {
+    const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+    const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+    const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+    const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+    const double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
+    const double dx = d.x, dy = d.y, dz = d.z;
+    const double a = dx * dx + dy * dy + dz * dz, hb = dx * ocx + dy * ocy + dz * ocz;
+    const double cc = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
+    double t64 = (double)t;
+    const double f = (a * t64 + 2.0 * hb) * t64 + cc, fp = 2.0 * (a * t64 + hb);
+    if (fabs(fp) > 1e-12) t64 -= f * (double)__builtin_amdgcn_rcpf((float)fp);    // |f / fp| ~ 1e-7 t: an f32 reciprocal is plenty
+    const double ir = 1.0 / rad;
+    return mk((float)((ocx + dx * t64) * ir), (float)((ocy + dy * t64) * ir), (float)((ocz + dz * t64) * ir));
+}
+
 // The reference's own operation sequence for one triangle (intersections.rs:123-126,153-166),
 // evaluated without FMA contraction.  Whether a ray that STARTS on a triangle re-hits it at
 // t ~ 0 (the reference accepts t >= 0 with no epsilon) is decided by rounding noise, and so is
@@ -697,7 +717,8 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
 // One thread per ray of iteration `it`.  last != 0: this is the last allowed bounce
 // (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
-// light-sampling branch of raytrace.rs:74-87 can continue the path.
+// light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
+// further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
 __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
@@ -762,13 +783,8 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                             v = a * uv[3] + b * uv[5] + c * uv[1];
                         }
                     } else {
-                        const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
-                        const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
-                        const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
-                        const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
-                        const float ir = (float)(1.0 / rad);
                         p = at_ref(o, d, t);                                               // intersections.rs:68
-                        nrm = mk((float)((double)p.x - cx), (float)((double)p.y - cy), (float)((double)p.z - cz)) * ir;  // intersections.rs:69
+                        nrm = sphere_normal(r0, r1, o, d, t);                              // intersections.rs:69
                     }
                 }
                 const float4 M0 = sc.materials[2 * mat], M1 = sc.materials[2 * mat + 1];
@@ -837,7 +853,7 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
             }
-        } else if (sc.n_lights) {
+        } else if (sc.n_lights && last == 1) {
             const uint32_t L = sc.n_lights;
             const uint32_t slot0 = block_alloc(fire, L, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (fire) {
@@ -881,9 +897,9 @@ __device__ __forceinline__ uint8_t to_output(float c) {
     if (v >= 255.f) return 255;
     return (uint8_t)v;
 }
-__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, uint32_t n_values, float inv_spp,
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, size_t n_values, float inv_spp,
                                                  uint8_t* __restrict__ rgb8, float* __restrict__ color) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_values) return;
     // f64::min(NaN, 1.0) == 1.0 in Rust, as fminf does here
     const float c = fminf(sqrtf(accum[i] * inv_spp), 1.0f);
@@ -891,10 +907,21 @@ __global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum
     if (rgb8) rgb8[i] = to_output(c);
 }
 
+// dst += src: the add of the multi-GPU exchange step (rt_accum_reduce), 16 bytes per lane
+__global__ __launch_bounds__(256) void k_accum_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(dst)[i], b = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] += src[n4 * 4 + threadIdx.x];
+}
+
 // per-pixel hit record for rt_primary_hits
 __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, RayQueue q, const float2* __restrict__ hits,
                                                   const uint32_t* __restrict__ ctl, uint32_t capacity, int32_t* __restrict__ obj,
-                                                  int32_t* __restrict__ tri, float* __restrict__ tout, float* __restrict__ nout) {
+                                                  int32_t* __restrict__ tri, float* __restrict__ tout, float* __restrict__ nout,
+                                                  float* __restrict__ dout) {
     const uint32_t n = min(ctl[CTL_QCOUNT + 0], capacity);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -905,6 +932,8 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     uint32_t x, row;
     if (__float_as_uint(H.y) == HIT_INVALID || !slot_to_pixel(sc, pp, pid % pp.npix_pad, x, row)) return;
     const size_t px = (size_t)row * sc.width + x;
+    if (dout) { dout[px * 3 + 0] = D.x; dout[px * 3 + 1] = D.y; dout[px * 3 + 2] = D.z; }   // the ray k_raygen made (rt_primary_rays)
+    if (!obj) return;
     const uint32_t code = __float_as_uint(H.y);
     int32_t o = -1, t = -1;
     float tt = -1.f;
@@ -924,14 +953,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
                 const float4 S = sc.smeta[4 * (size_t)code];
                 nrm = mk(S.x, S.y, S.z);
             } else {
-                const f3 org = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
-                const f3 p = org + d * tt;
-                const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
-                const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
-                const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
-                const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
-                const float ir = (float)(1.0 / rad);
-                nrm = mk((float)((double)p.x - cx), (float)((double)p.y - cy), (float)((double)p.z - cz)) * ir;
+                nrm = sphere_normal(r0, r1, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), tt);
             }
         }
     }
@@ -991,12 +1013,16 @@ void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const f
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
 }
-void launch_resolve(const float* accum, uint32_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st) {
+void launch_resolve(const float* accum, size_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(n_values, 256)), dim3(256), 0, st, accum, n_values, inv_spp, rgb8, color);
 }
 void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float2* hits, const uint32_t* ctl, uint32_t capacity,
-                     int32_t* obj, int32_t* tri, float* t, float* nrm, hipStream_t st) {
-    hipLaunchKernelGGL(k_hit_info, dim3(cdiv(pp.n_paths, 256)), dim3(256), 0, st, sc, pp, q, hits, ctl, capacity, obj, tri, t, nrm);
+                     int32_t* obj, int32_t* tri, float* t, float* nrm, float* dir, hipStream_t st) {
+    hipLaunchKernelGGL(k_hit_info, dim3(cdiv(pp.n_paths, 256)), dim3(256), 0, st, sc, pp, q, hits, ctl, capacity, obj, tri, t, nrm, dir);
+}
+void launch_accum_add(const LaunchCfg& cfg, float* dst, const float* src, size_t n, hipStream_t st) {
+    const uint32_t blocks = std::min<uint32_t>(cfg.n_cu * 8u, std::max<uint32_t>(1, cdiv(n / 4 + 1, 256)));
+    hipLaunchKernelGGL(k_accum_add, dim3(blocks), dim3(256), 0, st, dst, src, n);
 }
 void launch_calib_gather(const float4* table, uint32_t n_records, uint32_t iters, uint32_t blocks, float* sink, hipStream_t st) {
     hipLaunchKernelGGL(k_calib_gather, dim3(blocks), dim3(256), 0, st, table, n_records, iters, sink);

@@ -62,8 +62,14 @@ def scene_c3(width=1920, height=1080, seed=42):
     return dict(width=width, height=height, background=SKY, camera=RTIOW_CAMERA, objects=rtiow_spheres(seed))
 
 
-def torus_mesh(nu=1000, nv=500, center=(0.0, 1.6, 0.0), R=3.0, r=1.0, bump=0.05):
-    """Bumpy torus around the y axis: nu x nv quads -> 2*nu*nv triangles, nu*nv vertices."""
+def torus_mesh(nu=1000, nv=500, center=(0.0, 1.6, 0.0), R=3.0, r=1.0, bump=0.05, outward=True):
+    """Bumpy torus around the y axis: nu x nv quads -> 2*nu*nv triangles, nu*nv vertices.
+
+    outward: winding such that the geometric normal normalize((B-A) x (C-A)) (intersections.rs:169) points out of
+    the tube.  The reference never flips a normal towards the ray, so the winding decides where a Lambertian
+    surface scatters to: with outward=False (the round-1 generator) every path that reaches the torus is scattered
+    INTO the tube, stays trapped there for all `depth` bounces and returns black -- a valid scene of the reference,
+    but a black torus hides any bias of the image gates.  The default is the lit torus."""
     th = np.arange(nu, dtype=np.float64) * (2.0 * np.pi / nu)
     ph = np.arange(nv, dtype=np.float64) * (2.0 * np.pi / nv)
     T, P = np.meshgrid(th, ph, indexing="ij")
@@ -76,24 +82,28 @@ def torus_mesh(nu=1000, nv=500, center=(0.0, 1.6, 0.0), R=3.0, r=1.0, bump=0.05)
     j = np.arange(nv)[None, :]
     i1, j1 = (i + 1) % nu, (j + 1) % nv
     v00, v10, v01, v11 = i * nv + j, i1 * nv + j, i * nv + j1, i1 * nv + j1
-    t1 = np.stack([v00, v10, v11], axis=-1).reshape(-1, 3)
-    t2 = np.stack([v00, v11, v01], axis=-1).reshape(-1, 3)
+    if outward:
+        t1 = np.stack([v00, v11, v10], axis=-1).reshape(-1, 3)
+        t2 = np.stack([v00, v01, v11], axis=-1).reshape(-1, 3)
+    else:
+        t1 = np.stack([v00, v10, v11], axis=-1).reshape(-1, 3)
+        t2 = np.stack([v00, v11, v01], axis=-1).reshape(-1, 3)
     tris = np.empty((2 * nu * nv, 3), dtype=np.int64)
     tris[0::2], tris[1::2] = t1, t2
     return verts, tris
 
 
-def scene_c4(width=3840, height=2160, nu=1000, nv=500):
-    verts, tris = torus_mesh(nu, nv)
+def scene_c4(width=3840, height=2160, nu=1000, nv=500, outward=True):
+    verts, tris = torus_mesh(nu, nv, outward=outward)
     objs = [dict(type="Mesh", name="Torus", verts=verts, tris=tris, materials=[dict(type="Lambertian", albedo=[0.6, 0.6, 0.6])], mat_names=["M"]),
             dict(type="Plane", center=[0.0, 0.0, 0.0], normal=[0.0, 1.0, 0.0], material=dict(type="Lambertian", albedo=[0.2, 0.2, 0.2]))]
     cam = dict(eye=[6.0, 5.0, 8.0], look_at=[0.0, 1.2, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)
     return dict(width=width, height=height, background=SKY, camera=cam, objects=objs)
 
 
-def scene_c5(width=1920, height=1080, nu=1000, nv=500, seed=42):
+def scene_c5(width=1920, height=1080, nu=1000, nv=500, seed=42, outward=True):
     """C3 spheres + the C4 torus translated to (0, 1.6, -6); no ground plane."""
-    verts, tris = torus_mesh(nu, nv, center=(0.0, 1.6, -6.0))
+    verts, tris = torus_mesh(nu, nv, center=(0.0, 1.6, -6.0), outward=outward)
     objs = rtiow_spheres(seed)
     objs.append(dict(type="Mesh", name="Torus", verts=verts, tris=tris, materials=[dict(type="Lambertian", albedo=[0.6, 0.6, 0.6])], mat_names=["M"]))
     return dict(width=width, height=height, background=SKY, camera=RTIOW_CAMERA, objects=objs)

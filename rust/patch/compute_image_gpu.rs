@@ -2,12 +2,14 @@
 //! of bsati/raytracer-rust.  It keeps the reference's loading code (lines 114-125) and replaces the
 //! rayon loop (126-154) by one call into librtamd.so.  It needs three small additions to the
 //! reference: `pub` getters for the four private `Camera` fields (camera.rs:7-12), `pub` access to the
-//! material fields (materials.rs:40-43,68-71,90-94,155-159) and `image::write_rgb8` below.
+//! material fields (materials.rs:40-43,68-71,90-94,155-159), `image::read_image_bytes` (the decoding half of
+//! image.rs:166-173: the raw RGB8 bytes before `Color::from_output`) and `image::write_rgb8` below.
 //! The flattening mirrors `load_scene()` in raytracer-rust_amd/csrc/rt_host.cpp, which is the tested
 //! statement of the same logic.
 use rtamd_sys::*;
 use std::ptr;
 
+#[derive(Default)]
 struct Flat {
     mat_type: Vec<i32>, mat_rgb: Vec<f64>, mat_param: Vec<f64>, mat_texture: Vec<i32>,
     tex_w: Vec<u32>, tex_h: Vec<u32>, tex_data: Vec<Vec<u8>>,
@@ -24,10 +26,13 @@ fn push_material(f: &mut Flat, m: &Material) -> i32 {
         Material::Dieletrics(d) => (RT_MAT_DIELECTRIC, d.tint, d.refraction_index, -1),
         Material::Emissive(e) => (RT_MAT_EMISSIVE, e.color, 0.0, -1),
         Material::Texture(tm) => {
-            // pixel_colors were loaded by Scene::precompute (scene.rs:59-65); bytes = round(c * 255.999)
-            f.tex_w.push(tm.width as u32);
-            f.tex_h.push(tm.height as u32);
-            f.tex_data.push(tm.pixel_colors.iter().flat_map(|c| c.to_output()).collect());
+            // The library wants the decoded PNG bytes themselves (it applies byte / 255.999 on fetch, image.rs:45-51).
+            // They are read again from texture_path: rebuilding them from pixel_colors with to_output() is NOT exact,
+            // because to_output truncates (image.rs:37-43) and trunc(255.999 * (b / 255.999)) can come out as b - 1.
+            let (bytes, w, h) = image::read_image_bytes(Path::new(&tm.texture_path));   // Vec<u8> of w * h * 3
+            f.tex_w.push(w as u32);
+            f.tex_h.push(h as u32);
+            f.tex_data.push(bytes);
             (RT_MAT_TEXTURE, Color::new(0.0, 0.0, 0.0), 0.0, f.tex_w.len() as i32 - 1)
         }
     };

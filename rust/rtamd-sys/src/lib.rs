@@ -1,5 +1,8 @@
 //! Raw bindings to `include/rtamd.h`, field for field.  UNTESTED here (no Rust toolchain in the build
-//! environment); the struct layouts are the ones `tests/test_host.py` pins for the ctypes mirror.
+//! environment).  The struct layouts follow `abi_layout.json` beside this crate: size of every struct, offset and
+//! size of every field, as `tests/abi_check.c` pins them with `_Static_assert`s in a C11 build of the header and as
+//! `tests/test_abi.py` compares them with the ctypes mirror (`raytracer-rust_amd/lib.py`).  `#[repr(C)]` with the
+//! field types below reproduces exactly those offsets on LP64.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -16,6 +19,9 @@ pub const RT_MAT_EMISSIVE: i32 = 4;
 pub const RT_SSAA_UNIFORM: i32 = 0;
 pub const RT_SSAA_JITTER: i32 = 1;
 pub const RT_MAX_ITERATIONS: usize = 320;
+pub const RT_FLAG_COUNTERS: u32 = 1;
+pub const RT_FLAG_TIMING: u32 = 2;
+pub const RT_NOALLOC_SCRATCH_BYTES: usize = 64 << 20;
 
 #[repr(C)]
 pub struct rt_scene_desc {
@@ -98,6 +104,11 @@ extern "C" {
     pub fn rt_resolve(ctx: *mut rt_context, accum_dev: *const f32, spp_total: u32, rgb8_dev: *mut u8, color_dev: *mut f32, stream: *mut c_void) -> c_int;
     pub fn rt_render_image(ctx: *mut rt_context, params: *const rt_render_params, accum_host: *mut f32, rgb8_host: *mut u8) -> c_int;
     pub fn rt_primary_hits(ctx: *mut rt_context, dx: f64, dy: f64, object_id: *mut i32, triangle_id: *mut i32, t: *mut f32, normal_xyz: *mut f32) -> c_int;
+    pub fn rt_primary_rays(ctx: *mut rt_context, dx: f64, dy: f64, origin_xyz: *mut f32, dir_xyz: *mut f32) -> c_int;
+    pub fn rt_render_accumulate_noalloc(ctx: *mut rt_context, params: *const rt_render_params, accum_dev: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn rt_scene_upload_devices(ctxs: *const *mut rt_context, n: u32, scene: *const rt_scene_desc) -> c_int;
+    pub fn rt_accum_reduce(dst: *mut rt_context, dst_accum_dev: *mut f32, src: *const *mut rt_context, src_accum_dev: *const *const f32, n_src: u32, stream: *mut c_void) -> c_int;
+    pub fn rt_render_image_devices(ctxs: *const *mut rt_context, n: u32, params: *const rt_render_params, split_tiles: c_int, accum_host: *mut f32, rgb8_host: *mut u8) -> c_int;
     pub fn rt_get_stats(ctx: *mut rt_context, out: *mut rt_stats) -> c_int;
     pub fn rt_stats_reset(ctx: *mut rt_context) -> c_int;
     pub fn rt_debug_gather(ctx: *mut rt_context, table_bytes: u64, iters: u32, bytes_loaded: *mut f64) -> c_int;

@@ -49,36 +49,68 @@ def load_pair(name, ctx, width=None, height=None):
     return O.OracleScene.from_dict(d)
 
 
-def check_hits(got, want, allow_id_mismatch=0, curved=False):
-    """ids: exact (up to allow_id_mismatch); t and normal: within REL_TOL relative.
-    curved=True (scenes with spheres): the device ray direction is the f64 direction rounded to
-    f32 (4e-8 rad), and on a sphere the hit point moves by that angle * distance / cos(incidence),
-    so t and the normal are ill-conditioned at silhouettes.  There at most 1 % of the hit pixels
-    may exceed REL_TOL, and none may exceed 1e-3."""
+def check_hits(got, want, allow_id_mismatch=0):
+    """ids: exact (up to allow_id_mismatch); t and normal: within REL_TOL relative on EVERY hit, no allowance."""
     id_bad = (got["object_id"] != want["object_id"]) | (got["triangle_id"] != want["triangle_id"])
     assert id_bad.sum() <= allow_id_mismatch, "%d hit ids differ from the oracle" % id_bad.sum()
     ok = (want["object_id"] >= 0) & ~id_bad
-    assert np.all(got["t"][want["object_id"] < 0] == -1.0)
+    assert np.all(got["t"][(want["object_id"] < 0) & ~id_bad] == -1.0)
     if not ok.any():
         return int(id_bad.sum()), 0.0, 0.0
     rel_t = np.abs(got["t"][ok].astype(np.float64) - want["t"][ok]) / np.abs(want["t"][ok])
     nerr = np.linalg.norm(got["normal"][ok].astype(np.float64) - want["normal"][ok], axis=-1) / np.linalg.norm(want["normal"][ok], axis=-1)
-    for what, e in (("t", rel_t), ("normal", nerr)):
-        if curved:
-            frac = float((e >= REL_TOL).mean())
-            assert frac <= 0.01 and e.max() < 1e-3, "%s: %.3f %% of hits above %g, max %.3e" % (what, 100 * frac, REL_TOL, e.max())
-        else:
-            assert e.max() < REL_TOL, "max relative %s error %.3e" % (what, e.max())
+    assert rel_t.max() < REL_TOL, "max relative t error %.3e" % rel_t.max()
+    assert nerr.max() < REL_TOL, "max relative normal error %.3e" % nerr.max()
     return int(id_bad.sum()), float(rel_t.max()), float(nerr.max())
+
+
+def oracle_camera_dirs(osc, dx, dy, crop=None):
+    """camera.rs:62-67 + raytrace.rs:32-37 in numpy f64 from the oracle's camera: unit direction per pixel."""
+    cam = osc.camera()
+    x0, x1, r0, r1 = crop if crop is not None else (0, osc.width, 0, osc.height)
+    xs = np.arange(x0, x1, dtype=np.float64)[None, :, None] + dx
+    ys = (osc.height - 1 - np.arange(r0, r1, dtype=np.float64))[:, None, None] + dy          # raytrace.rs:128: row 0 is j = height-1
+    d = cam["lower_left"] + cam["horizontal"] * xs + cam["vertical"] * ys - cam["eye"]
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def hits_pair(ctx, osc, dx=0.0, dy=0.0, crop=None, own_camera_id_slack=None):
+    """(device hits, oracle hits) for one primary ray per pixel at sub-pixel offset (dx, dy).
+
+    The device works in f32 and the reference in f64, so the comparison is made in two links that are each strict:
+      1. the device's rays (rt_primary_rays) equal the oracle camera's rays (camera.rs:62-67) to f32 rounding
+         (|delta| <= 1e-7 per component) -- this pins Camera::spawn_ray / Ray::new;
+      2. the oracle is fed those very f32 rays (orc_closest_hits), so t and the normal of every hit can be held to
+         1e-5 with no allowance: an f32-rounded direction (4e-8 rad) is otherwise amplified by 1/cos(incidence) at
+         sphere silhouettes, which is a property of the ray, not of the intersection code.
+    own_camera_id_slack: also compare the ids with the oracle traced along its OWN f64 rays (at most that many
+    silhouette pixels may differ)."""
+    got = ctx.primary_hits(dx, dy)
+    o, d = ctx.primary_rays(dx, dy)
+    assert np.array_equal(o.astype(np.float64), osc.camera()["eye"].astype(np.float32).astype(np.float64))
+    if crop is not None:
+        x0, x1, r0, r1 = crop
+        got = {k: v[r0:r1, x0:x1] for k, v in got.items()}
+        d = d[r0:r1, x0:x1]
+    ref_d = oracle_camera_dirs(osc, dx, dy, crop)
+    assert np.abs(d.astype(np.float64) - ref_d).max() <= 1e-7, "device rays differ from camera.rs:62-67 by %.3e" % np.abs(d - ref_d).max()
+    want = osc.closest_hits(o.astype(np.float64), d.astype(np.float64))
+    if own_camera_id_slack is not None:
+        own = osc.closest_hits(osc.camera()["eye"], ref_d)      # (threaded; osc.primary_hits is the same thing on one core)
+        bad = ((got["object_id"] != own["object_id"]) | (got["triangle_id"] != own["triangle_id"])).sum()
+        assert bad <= own_camera_id_slack, "%d ids differ from the oracle traced along its own f64 rays" % bad
+    return got, want
 
 
 # ------------------------------------------------------------------ C2: the hit-id gate
 def test_c2_cube_primary_hits_bit_exact(ctx):
     osc = load_pair("cube", ctx)
     got = ctx.primary_hits(0.0, 0.0)
-    want = osc.primary_hits(0.0, 0.0)
+    want = osc.primary_hits(0.0, 0.0)                  # the oracle along its own f64 rays: the gate as BASELINE.json states it
     assert (want["triangle_id"] >= 0).sum() > 10000    # the cube is in view
     bad, rt_, rn = check_hits(got, want, allow_id_mismatch=0)
+    got2, want2 = hits_pair(ctx, osc, 0.0, 0.0, own_camera_id_slack=0)      # and along the device's f32 rays
+    check_hits(got2, want2, allow_id_mismatch=0)
     print("C2: ids exact, max rel t %.2e, normal %.2e" % (rt_, rn))
 
 
@@ -86,41 +118,42 @@ def test_c2_cube_primary_hits_bit_exact(ctx):
 def test_cube_primary_hits_other_offsets(ctx, off):
     osc = load_pair("cube", ctx)
     check_hits(ctx.primary_hits(*off), osc.primary_hits(*off), allow_id_mismatch=0)
+    check_hits(*hits_pair(ctx, osc, *off, own_camera_id_slack=0), allow_id_mismatch=0)
 
 
 def test_c1_spheres_primary_hits(ctx):
     osc = load_pair("spheres", ctx)
-    check_hits(ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0), allow_id_mismatch=0, curved=True)
+    check_hits(*hits_pair(ctx, osc, own_camera_id_slack=0), allow_id_mismatch=0)
 
 
 def test_c3_rtiow_primary_hits(ctx):
     sc = scenegen.scene_c3(width=480, height=270)
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
-    # silhouette rays may flip between f32 rays and the f64 oracle: report, allow a handful
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8, curved=True)
-    print("C3 480x270: %d id mismatches of %d" % (bad, got["t"].size))
+    # silhouette rays may flip between the f32 rays and the oracle's own f64 rays: allow a handful there
+    got, want = hits_pair(ctx, osc, own_camera_id_slack=8)
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=2)
+    print("C3 480x270: %d id mismatches of %d, max rel t %.2e, normal %.2e" % (bad, got["t"].size, rt_, rn))
 
 
 def test_c4_torus_primary_hits(ctx):
     sc = scenegen.scene_c4(width=192, height=108, nu=100, nv=50)    # 10,000 triangles: the oracle is brute force
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
+    got, want = hits_pair(ctx, osc, own_camera_id_slack=4)
     assert (want["triangle_id"] >= 0).sum() > 2000
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=4)
-    print("C4 (10k tris) 192x108: %d id mismatches" % bad)
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=2)
+    print("C4 (10k tris) 192x108: %d id mismatches, max rel t %.2e, normal %.2e" % (bad, rt_, rn))
 
 
 def test_c5_combined_primary_hits(ctx):
     sc = scenegen.scene_c5(width=240, height=135, nu=80, nv=40)     # 485 spheres + 6,400 triangles
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    got, want = ctx.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0)
+    got, want = hits_pair(ctx, osc, own_camera_id_slack=6)
     assert (want["triangle_id"] >= 0).sum() > 500 and (want["object_id"] == 0).sum() > 1000    # torus and ground in view
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=6, curved=True)
-    print("C5 (6.4k tris + spheres) 240x135: %d id mismatches" % bad)
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=2)
+    print("C5 (6.4k tris + spheres) 240x135: %d id mismatches, max rel t %.2e, normal %.2e" % (bad, rt_, rn))
 
 
 def test_deep_traversal_stack_spills_correctly(ctx):
@@ -134,7 +167,7 @@ def test_deep_traversal_stack_spills_correctly(ctx):
     order = np.random.default_rng(1).permutation(n)           # file order != depth order
     objs = [dict(type="Mesh", verts=verts, tris=tris[order], materials=[dict(type="Emissive", color=[1, 1, 1])])]
     osc = small_scene(ctx, objs, 48, 48)
-    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    got, want = hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=0)
     assert (want["triangle_id"] >= 0).sum() > 500
     check_hits(got, want)
     assert np.all(want["triangle_id"][want["triangle_id"] >= 0] == int(np.nonzero(order == 0)[0][0]))
@@ -156,7 +189,7 @@ def test_axis_parallel_rays_do_not_walk_the_tree(ctx):
                     [[idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)] for i in range(n) for j in range(n)])
     objs = [dict(type="Mesh", verts=verts, tris=tris, materials=[dict(type="Emissive", color=[1, 1, 1])])]
     osc = small_scene(ctx, objs, 65, 65)
-    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    got, want = hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=2)
     assert want["triangle_id"][32, 32] >= 0
     check_hits(got, want, allow_id_mismatch=2)    # rays through shared edges / vertices of the grid
     # a one-pixel-wide image: EVERY ray has d.x == 0 (measured with the shared bound: 98 nodes and
@@ -194,19 +227,21 @@ def test_converged_image_parity(ctx, name, n):
     bias = abs(np.mean(acc / spp) - np.mean(ref["sum"] / spp))
     print("%s: PSNR %.2f dB at %d spp, |mean radiance bias| %.2e" % (name, p, spp, bias))
     assert p >= 40.0
-    assert bias <= 1e-3 * max(1.0, np.mean(ref["sum"] / spp)) * 3
+    assert bias <= 1e-3
 
 
 def test_c3_image_parity_small(ctx):
     sc = scenegen.scene_c3(width=160, height=90)
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    n = 24
+    n = 32
     acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=5, seed=5))
     ref = osc.render(mode="jitter", N=n, depth=5, seed=23)
     p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
+    bias = abs(np.mean(acc) - np.mean(ref["sum"])) / (n * n)
+    assert bias <= 1e-3, bias
     print("C3 160x90: PSNR %.2f dB at %d spp" % (p, n * n))
-    assert p >= 38.0
+    assert p >= 40.0
 
 
 def test_c5_image_parity_small(ctx):
@@ -289,25 +324,52 @@ def test_ray_accounting_and_determinism(ctx):
     assert not np.array_equal(a, c)
 
 
-def test_full_size_c5_hits_and_properties(ctx):
-    """BASELINE.json's metric configuration at its full size: 485 spheres + 1,000,000 triangles at
-    1920x1080.  The brute-force oracle checks a 24x12-pixel window on the torus (288 rays x 1M
-    triangles); the whole frame is covered by size-independent properties: ray accounting, no queue
-    overflow, bit-identical repeat, tile-split union == full frame, sample-split linearity."""
+def window_image_parity(ctx, osc, n, windows, depth=5, what=""):
+    """Converged-image gate on windows of a full-size frame: the GPU renders the WHOLE frame at n*n spp, the oracle
+    (the reference's algorithm behind its conservative cull, bit-identical to the brute force) the windows, twice with
+    different seeds.  Per window: PSNR >= 40 dB, mean-abs error of the final colours <= the oracle's own seed-to-seed
+    mean-abs error + 1e-3, |bias of the mean radiance| <= 1e-3."""
+    spp = n * n
+    acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=depth, seed=11))
+    for (x0, x1, r0, r1) in windows:
+        a = osc.render_crop((x0, x1, r0, r1), mode="jitter", N=n, depth=depth, seed=101)["sum"][r0:r1, x0:x1]
+        b = osc.render_crop((x0, x1, r0, r1), mode="jitter", N=n, depth=depth, seed=202)["sum"][r0:r1, x0:x1]
+        g = acc[r0:r1, x0:x1].astype(np.float64)
+        ca, cb, cg = gamma(a, spp), gamma(b, spp), gamma(g, spp)
+        p, floor = psnr(cg, ca), psnr(cb, ca)
+        mae, mae_floor = np.abs(cg - ca).mean(), np.abs(cb - ca).mean()
+        bias = abs(g.mean() - 0.5 * (a.mean() + b.mean())) / spp
+        print("%s window x %d..%d rows %d..%d at %d spp: PSNR %.2f dB (oracle seed-to-seed %.2f), mean-abs %.2e (floor %.2e), |bias| %.2e, mean radiance %.3f"
+              % (what, x0, x1, r0, r1, spp, p, floor, mae, mae_floor, bias, a.mean() / spp))
+        assert a.mean() / spp > 0.02                 # the window is lit: a black window would pass any gate
+        assert p >= 40.0
+        assert mae <= mae_floor + 1e-3
+        assert bias <= 1e-3
+
+
+def test_full_size_c5_hits_image_and_properties(ctx):
+    """BASELINE.json's metric configuration at its full size: 485 spheres + 1,000,000 triangles at 1920x1080.
+    Every primary ray of the frame against the oracle (ids, t, normal); converged-image parity of two 32x32 windows
+    on the torus at 4096 spp -- the rays after the first bounce at the real tessellation (edges of 0.01 at
+    coordinates of 6), where the triangle self-hit quirk (t >= 0 with no epsilon, intersections.rs:166) is most
+    sensitive to rounding; then size-independent properties of the whole frame: ray accounting, no queue overflow,
+    bit-identical repeat, tile-split union == full frame, sample-split linearity."""
     sc = scenegen.scene_c5()
     assert sc["width"] == 1920 and sc["height"] == 1080
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
-    got = ctx.primary_hits(0.0, 0.0)
-    on_mesh = got["triangle_id"] >= 0
-    assert on_mesh.sum() > 20000 and (got["object_id"] >= 0).mean() > 0.5
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc), accel=True)
+    got, want = hits_pair(ctx, osc, own_camera_id_slack=64)
+    on_mesh = want["triangle_id"] >= 0
+    assert on_mesh.sum() > 20000 and (want["object_id"] >= 0).mean() > 0.5
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=16)
+    print("C5 1920x1080, all %d primary rays: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e"
+          % (got["t"].size, bad, on_mesh.sum(), rt_, rn))
     rows, cols = np.nonzero(on_mesh)
     r0, c0 = int(np.median(rows)), int(np.median(cols))
-    crop = (c0 - 12, c0 + 12, r0 - 6, r0 + 6)                       # x0, x1, row0, row1
-    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    want = osc.primary_hits(0.0, 0.0, crop=crop)
-    sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
-    assert (want["triangle_id"] >= 0).sum() > 100
-    check_hits(sub_, want, allow_id_mismatch=2, curved=True)
+    edge_r = int(rows.max()) - 8                                        # lower silhouette of the torus against the ground
+    edge_c = int(np.median(cols[rows >= edge_r]))
+    windows = [(c0 - 16, c0 + 16, r0 - 16, r0 + 16), (edge_c - 16, edge_c + 16, edge_r - 16, edge_r + 16)]
+    window_image_parity(ctx, osc, 64, windows, what="C5 1080p")
     one = dict(depth=5, seed=3, sample_begin=0, sample_end=1)          # 1 spp of a jitter:2 grid
     ctx.stats_reset()
     full, _ = ctx.render_image(rt.RenderParams("jitter:2", **one))
@@ -326,32 +388,38 @@ def test_full_size_c5_hits_and_properties(ctx):
     assert np.allclose(full + b, two, rtol=1e-5, atol=1e-6)
 
 
-def test_full_size_c3_and_c4_hit_windows(ctx):
-    """The other two BASELINE configurations at their full sizes: C3 (RTIOW spheres, 1920x1080) and C4
-    (1,000,000-triangle torus + plane, 3840x2160): windows of the frame against the brute-force oracle."""
+def test_full_size_c3_hits(ctx):
+    """C3 (RTIOW spheres) at 1920x1080: every primary ray against the oracle."""
     sc = scenegen.scene_c3()
     assert (sc["width"], sc["height"]) == (1920, 1080)
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
-    got = ctx.primary_hits(0.0, 0.0)
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    for crop in ((860, 1060, 500, 600), (0, 160, 980, 1080), (1700, 1920, 0, 60)):      # x0, x1, row0, row1
-        want = osc.primary_hits(0.0, 0.0, crop=crop)
-        sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
-        check_hits(sub_, want, allow_id_mismatch=4, curved=True)
+    got, want = hits_pair(ctx, osc, own_camera_id_slack=64)
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8)
+    print("C3 1920x1080, all %d primary rays: %d id mismatches, max rel t %.2e, normal %.2e" % (got["t"].size, bad, rt_, rn))
+
+
+def test_full_size_c4_hits_and_image(ctx):
+    """C4 (1,000,000-triangle torus + plane) at 3840x2160: the primary rays of the middle 1920x1080 of the frame and
+    of its left border against the oracle, and converged-image parity of two windows at 4096 spp."""
     sc = scenegen.scene_c4()
     assert (sc["width"], sc["height"]) == (3840, 2160)
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
-    got = ctx.primary_hits(0.0, 0.0)
-    on_mesh = got["triangle_id"] >= 0
-    assert on_mesh.sum() > 500000 and (got["object_id"] >= 0).mean() > 0.6        # torus and plane fill the frame
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc), accel=True)
+    got, want = hits_pair(ctx, osc, crop=(960, 2880, 540, 1620), own_camera_id_slack=64)
+    on_mesh = want["triangle_id"] >= 0
+    assert on_mesh.mean() > 0.5                                          # the torus fills the middle of the frame
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=16)
+    print("C4 3840x2160, middle 1920x1080: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e" % (bad, on_mesh.sum(), rt_, rn))
+    check_hits(*hits_pair(ctx, osc, crop=(0, 400, 0, 2160), own_camera_id_slack=16), allow_id_mismatch=4)
     rows, cols = np.nonzero(on_mesh)
-    r0, c0 = int(np.median(rows)), int(np.median(cols))
-    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-    for crop in ((c0 - 10, c0 + 10, r0 - 6, r0 + 6), (int(cols.min()) - 4, int(cols.min()) + 12, int(rows[cols.argmin()]) - 4, int(rows[cols.argmin()]) + 4)):
-        crop = (max(crop[0], 0), min(crop[1], 3840), max(crop[2], 0), min(crop[3], 2160))
-        want = osc.primary_hits(0.0, 0.0, crop=crop)
-        sub_ = {k: v[crop[2]:crop[3], crop[0]:crop[1]] for k, v in got.items()}
-        check_hits(sub_, want, allow_id_mismatch=2)
+    r0, c0 = 540 + int(np.median(rows)), 960 + int(np.median(cols))
+    # second window: the contact region of torus and plane below the middle of the frame (interreflection)
+    hit_plane = (want["object_id"] == 1)
+    pr, pc = np.nonzero(hit_plane)
+    w2 = (960 + int(np.median(pc)), 540 + int(np.median(pr))) if len(pr) else (c0, r0 + 200)
+    windows = [(c0 - 16, c0 + 16, r0 - 16, r0 + 16), (w2[0] - 16, w2[0] + 16, w2[1] - 16, w2[1] + 16)]
+    window_image_parity(ctx, osc, 64, windows, what="C4 4K")
 
 
 def test_device_pointer_api_matches_host_api(ctx):
@@ -425,7 +493,7 @@ def test_gpu_built_bvh_gives_the_same_hits_and_image(ctx):
         sc = scenegen.scene_c5(width=240, height=135, nu=80, nv=40)     # 485 spheres + 6,400 triangles
         fresh.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
         osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
-        check_hits(fresh.primary_hits(0.0, 0.0), osc.primary_hits(0.0, 0.0), allow_id_mismatch=6, curved=True)
+        check_hits(*hits_pair(fresh, osc, own_camera_id_slack=6), allow_id_mismatch=2)
         gpu_img, _ = fresh.render_image(rt.RenderParams("jitter:2", depth=5, seed=11))
         fresh.set_bvh_builder("host")
         fresh.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
@@ -473,7 +541,7 @@ def test_single_primitives_and_odd_sizes(ctx):
                   dict(type="Plane", center=[0, -1, 0], normal=[0, 1, 0], material=dict(type="Emissive", color=[0.5, 0.5, 0.5]))]):
         for (w, h) in ((1, 1), (37, 21), (8, 8)):
             osc = small_scene(ctx, objs, w, h)
-            check_hits(ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5), curved=True)
+            check_hits(*hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=0))
             # purely emissive scenes are deterministic at the uniform grid: images must agree to the byte
             _, rgb = ctx.render_image(rt.RenderParams("grid:2", depth=3))
             want = osc.render(mode="uniform", N=2, depth=3)["rgb8"]
@@ -504,9 +572,9 @@ def test_random_soups_match_the_oracle(ctx, seed):
         objs.append(dict(type="Sphere", center=[0.0, -500.5, 0.0], radius=498.0, material=dict(type="Lambertian", albedo=[0.3, 0.3, 0.3])))
         objs.append(dict(type="Plane", center=[0.0, 0.0, -6.0], normal=[0.0, 0.2, 1.0], material=dict(type="Lambertian", albedo=[0.2, 0.2, 0.2])))
     osc = small_scene(ctx, objs, 160, 120)
-    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
+    got, want = hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=6)
     assert (want["object_id"] >= 0).mean() > 0.2
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=6, curved=True)
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=3)
     print("soup %d: %d objects, %d id mismatches of %d, max rel t %.2e" % (seed, len(objs), bad, got["t"].size, rt_))
     # the same scene through the GPU-built BVH gives the same hits
     ctx.set_bvh_builder("gpu")
@@ -567,35 +635,51 @@ def test_tie_break_prefers_lower_object_index(ctx):
             dict(type="Sphere", center=[0, 0, -4], radius=1.0, material=dict(type="Emissive", color=[0, 0, 1])),
             dict(type="Sphere", center=[0, 0, -4], radius=1.0, material=dict(type="Emissive", color=[1, 1, 1]))]
     osc = small_scene(ctx, objs, 64, 64)
-    got, want = ctx.primary_hits(0.5, 0.5), osc.primary_hits(0.5, 0.5)
-    check_hits(got, want, curved=True)
+    got, want = hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=0)
+    check_hits(got, want)
     assert set(np.unique(got["object_id"])) <= {-1, 0, 2}
 
 
 def test_dropped_shadow_rays_are_an_error(ctx):
-    """raytrace.rs:64-87: on the last bounce a path fires with probability 0.1 * L and then spawns L
-    shadow rays, each of which can fire again.  With 8 lights that is 6.4 rays per path and
-    generation, more than the queues hold (4 per path): the render must say so, not return a
-    darker image."""
+    """raytrace.rs:64-87: on the last bounce a path fires with probability 0.1 * L and then spawns L shadow rays, each
+    of which can fire again: 0.1 * L * L successors per shadow ray that lands on a scatterer.  The queues hold L rays
+    per path, so the first generation always fits; with 8 lights HIDDEN behind a wall every shadow ray lands on a
+    scatterer and the process grows 6.4-fold per generation (the reference would recurse without bound): the render
+    must say so, not return a darker image -- and it must say so whatever the context rendered before."""
     grey = dict(type="Lambertian", albedo=[0.5, 0.5, 0.5])
     # a closed room of six planes around the camera: every primary ray scatters
-    objs = [dict(type="Plane", center=c, normal=n, material=grey) for c, n in
+    room = [dict(type="Plane", center=c, normal=n, material=grey) for c, n in
             (([0, -1, 0], [0, 1, 0]), ([0, 3, 0], [0, -1, 0]), ([-5, 0, 0], [1, 0, 0]), ([5, 0, 0], [-1, 0, 0]),
              ([0, 0, -4], [0, 0, 1]), ([0, 0, 6], [0, 0, -1]))]
-    for k in range(8):
-        objs.append(dict(type="Sphere", center=[-3.5 + k, 2.0, -1.0], radius=0.3, material=dict(type="Emissive", color=[1, 1, 1])))
-    fresh = rt.Context(0)        # queues sized by this render only (a context keeps its largest queues)
-    try:
-        small_scene(fresh, objs, 64, 64)
-        with pytest.raises(Exception, match="dropped"):
-            fresh.render_image(rt.RenderParams("jitter:4", depth=1, seed=1))
-        # two lights (the reference's scenes): fine
-        small_scene(fresh, objs[:8], 64, 64)
-        fresh.stats_reset()
-        fresh.render_image(rt.RenderParams("jitter:4", depth=1, seed=1))
-        assert fresh.stats()["queue_overflow"] == 0
-    finally:
-        fresh.close()
+    inside = [dict(type="Sphere", center=[-3.5 + k, 2.0, -1.0], radius=0.3, material=dict(type="Emissive", color=[1, 1, 1])) for k in range(8)]
+    outside = [dict(type="Sphere", center=[-3.5 + k, 9.0, -1.0], radius=0.3, material=dict(type="Emissive", color=[1, 1, 1])) for k in range(8)]
+    p = rt.RenderParams("jitter:4", depth=1, seed=1)
+    for warm in (False, True):
+        fresh = rt.Context(0)
+        try:
+            if warm:     # a context that has rendered a much bigger pass before behaves the same
+                small_scene(fresh, room + inside[:2], 256, 256)
+                fresh.render_image(rt.RenderParams("jitter:8", depth=2, seed=1))
+            small_scene(fresh, room + outside, 64, 64)
+            with pytest.raises(Exception, match="dropped"):
+                fresh.render_image(p)
+            # cutting the process off after the first generation is the documented remedy: nothing is dropped
+            fresh.stats_reset()
+            fresh.render_image(rt.RenderParams("jitter:4", depth=1, seed=1, max_shadow_generations=1))
+            assert fresh.stats()["queue_overflow"] == 0
+            # 8 visible lights: shadow rays end on the emitters, the process dies out, nothing is dropped
+            small_scene(fresh, room + inside, 64, 64)
+            fresh.stats_reset()
+            fresh.render_image(p)
+            st = fresh.stats()
+            assert st["queue_overflow"] == 0 and st["rays_per_iteration"][1] > 64 * 64 * 16 * 4     # ~0.8 * 8 shadow rays per path
+            # two lights (the reference's scenes): fine
+            small_scene(fresh, room + inside[:2], 64, 64)
+            fresh.stats_reset()
+            fresh.render_image(p)
+            assert fresh.stats()["queue_overflow"] == 0
+        finally:
+            fresh.close()
 
 
 def test_invalid_arguments_are_errors(ctx):

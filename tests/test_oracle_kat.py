@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle_py as O
+from util import GOLDEN
 
 L = O.lib()
 
@@ -343,3 +344,51 @@ def test_oracle_image_close_to_goldens(golden_dir):
         psnr = 10 * np.log10(255.0 ** 2 / mse)
         print(name, "PSNR vs golden", psnr)
         assert psnr > thresh
+
+
+# ---------------------------------------------------------------------------
+# The oracle's conservative cull (rt_oracle.cpp header, orc_enable_accel): test infrastructure that lets the
+# full-size parity tests afford the 1,000,000-triangle mesh.  It must not change a single bit of any result.
+# ---------------------------------------------------------------------------
+def test_oracle_cull_is_bit_identical_to_the_brute_force_loop():
+    import importlib
+    scenegen = importlib.import_module("raytracer-rust_amd.scenegen")
+    rng = np.random.default_rng(3)
+    cases = []
+    # the reference's own mesh scene (textured cube), a bumpy torus + spheres, and a soup with slivers, coincident
+    # triangles (exact ties: the lower index must win) and a zero-area triangle (M == 0: NaN passes the reject test)
+    cases.append(O.load_scene_dict(os.path.join(GOLDEN, "scenes", "cube", "cube.yaml"), base_dir=GOLDEN))
+    cases.append(scenegen.to_oracle_dict(scenegen.scene_c5(width=96, height=54, nu=60, nv=30)))
+    nt = 400
+    centre = rng.uniform(-2.0, 2.0, size=(nt, 1, 3))
+    verts = (centre + 10.0 ** rng.uniform(-2.0, 0.0, size=(nt, 1, 1)) * rng.normal(size=(nt, 3, 3))).reshape(-1, 3)
+    verts[:60] *= np.array([1.0, 1.0, 1e-3])
+    tris = np.arange(3 * nt).reshape(nt, 3)
+    tris = np.concatenate([tris, tris[100:110], [[0, 0, 1]]])          # duplicates and a degenerate triangle
+    cam = dict(eye=[0.0, 0.0, 6.0], look_at=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0], fovy=45.0)
+    cases.append(dict(width=80, height=60, background=[0.2, 0.3, 0.4], camera=cam, objects=[
+        dict(type="Mesh", materials=[dict(type="Lambertian", albedo=[0.7, 0.6, 0.5])],
+             mesh=dict(verts_np=verts, tris_np=tris, tri_mat_np=np.zeros(len(tris), np.int64))),
+        dict(type="Sphere", center=[0.0, 0.0, -3.0], radius=1.0, material=dict(type="Metal", albedo=[0.9, 0.9, 0.9], fuzziness=0.0))]))
+    for d in cases:
+        brute, culled = O.OracleScene.from_dict(d), O.OracleScene.from_dict(d, accel=True)
+        a, b = brute.primary_hits(0.25, 0.75), culled.primary_hits(0.25, 0.75)
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        ra = brute.render(mode="jitter", N=2, depth=4, seed=5, threads=4)
+        rb = culled.render(mode="jitter", N=2, depth=4, seed=5, threads=4)
+        assert ra["rays"] == rb["rays"]
+        assert np.array_equal(ra["sum"], rb["sum"], equal_nan=True) and np.array_equal(ra["rgb8"], rb["rgb8"])
+        # arbitrary rays, among them axis-parallel ones and rays that start on the geometry
+        o = rng.uniform(-3, 3, size=(2000, 3))
+        dirs = rng.normal(size=(2000, 3))
+        dirs[:300, 0] = 0.0
+        dirs[300:500, 1:] = 0.0
+        ha, hb = brute.closest_hits(o, dirs, threads=4), culled.closest_hits(o, dirs, threads=4)
+        for k in ha:
+            assert np.array_equal(ha[k], hb[k], equal_nan=True), k
+        hit = ha["object_id"] >= 0
+        o2, d2 = ha["point"][hit], rng.normal(size=(int(hit.sum()), 3))
+        ha, hb = brute.closest_hits(o2, d2, threads=4), culled.closest_hits(o2, d2, threads=4)
+        for k in ha:
+            assert np.array_equal(ha[k], hb[k], equal_nan=True), k
