@@ -126,7 +126,7 @@ void free_scene(rt_context* ctx) {
 
 void free_state(rt_context* ctx) {
     for (int k = 0; k < 2; ++k) {
-        (void)hipFree(ctx->q[k].a); (void)hipFree(ctx->q[k].b); (void)hipFree(ctx->q[k].c);
+        (void)hipFree(ctx->q[k].a); (void)hipFree(ctx->q[k].b); (void)hipFree(ctx->q[k].c); (void)hipFree(ctx->q[k].e);
         ctx->q[k] = RayQueue{};
     }
     (void)hipFree(ctx->hits); ctx->hits = nullptr;
@@ -142,6 +142,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].a, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].b, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].c, (size_t)capacity * sizeof(float4)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].e, (size_t)capacity * 2 * sizeof(double2)));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
@@ -239,7 +240,7 @@ struct FlatScene {
     std::vector<uchar4> texels;
     uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0;
     float bg[3], eye[3];
-    double lle[3], hz[3], vt[3];
+    double eye64[3], lle[3], hz[3], vt[3];
     uint32_t width = 0, height = 0, stack_depth = 2, bvh_depth = 0;
     double bvh_build_ms = 0;
 };
@@ -348,11 +349,11 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
     // ---- records: BVH primitives in leaf order, then the big spheres
     std::vector<float4>& prims = f.prims;
     std::vector<int4>& meta = f.meta;
-    std::vector<float4>& smeta = f.smeta;   // 64-byte shading records: (normal, material | flags) + a copy of the primitive record
+    std::vector<float4>& smeta = f.smeta;   // 96-byte shading records: (normal, material | flags) + the reference's f64 operands (rt_device.h)
     std::vector<float>& uvs = f.uvs;
     prims.assign((size_t)n_prims * 3, make_float4(0.f, 0.f, 0.f, 0.f));
     meta.assign(n_prims, make_int4(0, 0, 0, 0));
-    smeta.assign((size_t)n_prims * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    smeta.assign((size_t)n_prims * SMETA_WORDS, make_float4(0.f, 0.f, 0.f, 0.f));
     uvs.clear();
     for (uint32_t k = 0; k < n_prims; ++k) {
         uint32_t src = k < n_leaf_prims ? bvh_src[bvh.order[k]] : big_src[k - n_leaf_prims];
@@ -365,7 +366,8 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
             meta[k] = make_int4(d->sphere_object[src], -1, d->sphere_material[src], -1);
             uint32_t mw = (uint32_t)d->sphere_material[src] | SMETA_SPHERE;
             float mf; std::memcpy(&mf, &mw, 4);
-            smeta[(size_t)k * 4] = make_float4(0.f, 0.f, 0.f, mf);
+            smeta[(size_t)k * SMETA_WORDS] = make_float4(0.f, 0.f, 0.f, mf);
+            std::memcpy(&smeta[(size_t)k * SMETA_WORDS + 1], v, 32);
         } else {
             uint64_t t = src - d->n_spheres;
             const float* v = &tri_f32[9 * t];
@@ -392,9 +394,11 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
             if (nl > 0.0) { nn[0] /= nl; nn[1] /= nl; nn[2] /= nl; }
             uint32_t mw = (uint32_t)d->tri_material[t] | (has_uv ? SMETA_HAS_UV : 0u);
             float mf; std::memcpy(&mf, &mw, 4);
-            smeta[(size_t)k * 4] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], mf);
+            smeta[(size_t)k * SMETA_WORDS] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], mf);
+            // the reference's own operands, in its own number type: A, ab = B - A, ac = C - A (intersections.rs:149-154)
+            const double ops[10] = {V[0], V[1], V[2], ab[0], ab[1], ab[2], ac[0], ac[1], ac[2], 0.0};
+            std::memcpy(&smeta[(size_t)k * SMETA_WORDS + 1], ops, sizeof(ops));
         }
-        for (int q = 0; q < 3; ++q) smeta[(size_t)k * 4 + 1 + q] = r[q];
     }
     std::vector<float4>& nodes = f.nodes;
     nodes.assign(bvh.nodes.size() * 4, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -444,6 +448,7 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
     for (int k = 0; k < 3; ++k) {
         f.bg[k] = (float)d->background[k];
         f.eye[k] = (float)d->cam_eye[k];
+        f.eye64[k] = d->cam_eye[k];
         f.lle[k] = d->cam_lower_left[k] - d->cam_eye[k];
         f.hz[k] = d->cam_horizontal[k];
         f.vt[k] = d->cam_vertical[k];
@@ -473,7 +478,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     sc.n_nodes = f.n_nodes;
     sc.n_planes = f.n_planes;
     sc.n_lights = f.n_lights;
-    for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.lle[k] = f.lle[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
+    for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.eye64[k] = f.eye64[k]; sc.lle[k] = f.lle[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
     sc.width = f.width; sc.height = f.height;
     sc.stack_depth = f.stack_depth;
     sc.spill_levels = sc.stack_depth > LDS_STACK ? sc.stack_depth - LDS_STACK : 0;
@@ -535,7 +540,8 @@ static inline size_t align256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 // bytes of static scratch a pass of `paths` paths needs (rtamd.h: RT_NOALLOC_SCRATCH_BYTES)
 static size_t noalloc_bytes(uint32_t paths, uint32_t per_path) {
     const size_t cap = (size_t)paths * per_path;
-    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + align256(cap * sizeof(float2)) + align256((size_t)paths * sizeof(float4));
+    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + 2 * align256(cap * 2 * sizeof(double2)) +
+           align256(cap * sizeof(float2)) + align256((size_t)paths * sizeof(float4));
 }
 
 // One call = raytrace.rs:126-143 for a sample range and a tile set (see rtamd.h).
@@ -581,6 +587,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             ws.q[k].a = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].b = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].c = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
+            ws.q[k].e = reinterpret_cast<double2*>(carve(cap * 2 * sizeof(double2)));
         }
         ws.hits = reinterpret_cast<float2*>(carve(cap * sizeof(float2)));
         ws.radiance = reinterpret_cast<float4*>(carve((size_t)paths * sizeof(float4)));

@@ -11,6 +11,8 @@ constexpr uint32_t HIT_PLANE_BIT = 0x80000000u;  // hit code: plane index in the
 constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primitive
 constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: not a ray
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
+constexpr uint32_t SRC_SELF_BIT = 0x40000000u;  // src = SRC_SELF_BIT | triangle: the ray re-hits the triangle it starts on at t ~ 0 (decided by k_shade, see there)
+constexpr uint32_t SRC_PRIM_MASK = 0x0FFFFFFFu; // primitive index of such a src (rt_scene_upload limits primitives to 2^28)
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
 constexpr uint32_t SMETA_HAS_UV = 0x80000000u;
 constexpr uint32_t SMETA_SPHERE = 0x40000000u;
@@ -39,10 +41,13 @@ static_assert(CTL_NODES_LO % 2 == 0 && CTL_PRIMS_LO % 2 == 0, "64-bit counters m
 //   a = (o.x, o.y, o.z, d.x)
 //   b = (d.y, d.z, bits(src prim code), bits(path id))      -- a,b: all the closest-hit kernel reads
 //   c = (throughput.r, .g, .b, bits(rng state))
+//   e = two words per slot, touched only by rays with SRC_SELF_BIT: the f64 origin (x, y | z, 0) of which `a` holds the
+//       f32 rounding -- whether such a ray re-hits its triangle AGAIN depends on the last bits of that point
 struct RayQueue {
     float4* a;
     float4* b;
     float4* c;
+    double2* e;
 };
 
 // Primitive record, 48 bytes = 3 x float4, stored in BVH leaf order.
@@ -53,11 +58,16 @@ struct RayQueue {
 // index): the tie-break key of scene.rs:43 / intersections.rs:170.
 //
 // meta (int4 per primitive, leaf order): (object index, triangle index or -1, material, uv offset or -1)
-// smeta (4 x float4 = one 64-byte line per primitive, leaf order), what shading gathers:
-//   [0] = (n.x, n.y, n.z, bits(material | SMETA_HAS_UV | SMETA_SPHERE)), [1..3] = copy of the primitive record.
+// smeta (SMETA_WORDS x float4 = 96 bytes per primitive, leaf order), what shading gathers:
+//   [0] = (n.x, n.y, n.z, bits(material | SMETA_HAS_UV | SMETA_SPHERE))
+//   triangle: [1..5] = the reference's own f64 operands A, ab = B - A, ac = C - A (intersections.rs:149-154) as
+//             nine doubles (A.x A.y | A.z ab.x | ab.y ab.z | ac.x ac.y | ac.z 0): k_shade evaluates the hit point
+//             and the self-intersection of the next ray with the reference's f64 operation sequence (see there)
+//   sphere:   [1..2] = (c.x c.y | c.z radius) as doubles
 //   n = the triangle's unit normal, normalized((B-A) x (C-A)) (intersections.rs:169) evaluated in f64 on
 //   the host and rounded once.  The device's edges come from f32 vertices: on a 1M-triangle mesh (edges of
 //   0.01 at coordinates of 6) their cross product is off by 1.5e-5, above the 1e-5 bar.  Spheres: n unused.
+constexpr uint32_t SMETA_WORDS = 6;
 struct DevScene {
     const float4* nodes;      // 4 x 16 bytes per 4-wide quantised node (bvh.h)
     const float4* prims;      // 3 x float4 per primitive
@@ -77,6 +87,7 @@ struct DevScene {
     uint32_t n_lights;
     float bg[3];
     float eye[3];
+    double eye64[3];          // the reference's own f64 eye: origin of the primary rays in k_shade's f64 hit-point arithmetic
     // primary-ray directions are formed in f64 (the reference's type) and rounded once:
     // an f32 camera loses 1e-4 relative in t on grazing rays
     double lle[3], hz[3], vt[3];          // lle = lower_left - eye

@@ -238,48 +238,68 @@ __device__ __forceinline__ f3 sphere_normal(const float4 r0, const float4 r1, f3
     return mk((float)((ocx + dx * t64) * ir), (float)((ocy + dy * t64) * ir), (float)((ocz + dz * t64) * ir));
 }
 
-// The reference's own operation sequence for one triangle (intersections.rs:123-126,153-166),
-// evaluated without FMA contraction.  Whether a ray that STARTS on a triangle re-hits it at
-// t ~ 0 (the reference accepts t >= 0 with no epsilon) is decided by rounding noise, and so is
-// the side of the surface the hit point o + d*t lands on; both depend on the exact sequence of
-// roundings.  Using the reference's sequence for these two values makes the f32 statistics the
-// same as the f64 reference's (measured with the oracle's f32 instantiation).
-__device__ __forceinline__ float det3_ref(f3 v1, f3 v2, f3 v3) {
+// ---- The triangle arithmetic of the reference, in its own number type (f64) and its own operation sequence
+// (intersections.rs:123-126,153-172), without FMA contraction.
+//
+// The reference accepts a triangle hit at t >= 0 with NO epsilon (intersections.rs:166), so a ray that STARTS on a
+// triangle re-hits it at t ~ 1e-16 whenever rounding puts its origin on the near side.  That is not a coin toss: the
+// origin p = o + d * t0 was computed from the same determinants, and the correlation between the roundings of t0 and
+// of det(p - A, ab, ac) gives every triangle and viewpoint its own re-hit probability (measured on the reference's
+// algorithm: 0.14 ... 1.0; after a first re-hit 0.6 ... 0.97 for the next one).  A re-hit shades the surface again
+// (a Lambertian bounce costs another factor of albedo, a Texture front face becomes an emitting back face), so a
+// converged image of a mesh depends on these probabilities.  They can only be reproduced by doing what the reference
+// does: k_shade therefore evaluates t0, the hit point and the self-intersection of the ray it emits with the
+// reference's f64 sequence on the reference's f64 operands A, ab, ac (smeta), and hands the verdict to the next
+// iteration's closest-hit kernel in the ray's src word (SRC_SELF_BIT), together with the f64 hit point (queue word e),
+// whose last bits decide the re-hits that follow.  The rays themselves stay f32; where an f32 ray enters the f64
+// sequence its 29 missing mantissa bits are filled with random bits (dither64): operands with trailing zeros make
+// half of the sequence's products exact and shift the probabilities (0.13 instead of 0.36 on one test triangle),
+// while random low bits are what the reference's own f64 rays carry.  (The same sequence in f32 -- round 1 -- gave
+// 0.05 ... 0.95 where the reference has 0.3; it only happened to agree on scenes/cube, whose coordinates are exact.)
+struct d3 {
+    double x, y, z;
+};
+__device__ __forceinline__ d3 mkd(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ double det3_ref(d3 v1, d3 v2, d3 v3) {
 #pragma clang fp contract(off)
     return (v1.x * v2.y * v3.z + v2.x * v3.y * v1.z + v3.x * v1.y * v2.z) - (v3.x * v2.y * v1.z + v2.x * v1.y * v3.z + v1.x * v3.y * v2.z);
 }
-__device__ __forceinline__ f3 sub_ref(f3 a, f3 b) {
+__device__ __forceinline__ d3 sub_ref(d3 a, d3 b) {
 #pragma clang fp contract(off)
-    return mk(a.x - b.x, a.y - b.y, a.z - b.z);
+    return mkd(a.x - b.x, a.y - b.y, a.z - b.z);
 }
-// t = -(Mt / M) only
-__device__ __forceinline__ float tri_t_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac) {
+// raytrace.rs:40-42: origin + direction * t, two roundings per component
+__device__ __forceinline__ d3 at_ref(d3 o, d3 d, double t) {
 #pragma clang fp contract(off)
-    const f3 res = sub_ref(o, A);
-    return -(det3_ref(res, ab, ac) / det3_ref(d, ab, ac));
+    return mkd(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
-__device__ __forceinline__ bool tri_hit_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac, float& t, float& a, float& b) {
+__device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {   // the same in f32, for hits on spheres and planes
 #pragma clang fp contract(off)
-    const f3 res = sub_ref(o, A);
-    const float m = det3_ref(d, ab, ac), mt = det3_ref(res, ab, ac), ma = det3_ref(d, res, ac), mb = det3_ref(d, ab, res);
+    return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+}
+// one iteration of the loop of intersections.rs:148-186: a = Ma / M, b = Mb / M, t = -(Mt / M); true = the candidate
+// passes the reject test of line 166 (a NaN candidate, M == 0, is not taken: the reference takes it only while it
+// has no other hit, and a ray parallel to the triangle it starts on leaves it)
+__device__ __forceinline__ bool tri_hit_ref(d3 o, d3 d, d3 A, d3 ab, d3 ac, double& t, double& a, double& b) {
+#pragma clang fp contract(off)
+    const d3 res = sub_ref(o, A);
+    const double m = det3_ref(d, ab, ac), mt = det3_ref(res, ab, ac), ma = det3_ref(d, res, ac), mb = det3_ref(d, ab, res);
     a = ma / m;
     b = mb / m;
     t = -(mt / m);
-    // NaN (M == 0) is rejected here; the reference would accept it when no hit exists yet
-    return a >= 0.f && b >= 0.f && a + b <= 1.f && t >= 0.f;
+    return a >= 0.0 && b >= 0.0 && a + b <= 1.0 && t >= 0.0;
 }
-// a = Ma / M, b = Mb / M only (intersections.rs:155-160)
-__device__ __forceinline__ void tri_ab_ref(f3 o, f3 d, f3 A, f3 ab, f3 ac, float& a, float& b) {
-#pragma clang fp contract(off)
-    const f3 res = sub_ref(o, A);
-    const float m = det3_ref(d, ab, ac);
-    a = det3_ref(d, res, ac) / m;
-    b = det3_ref(d, ab, res) / m;
+// f32 value -> f64 with random bits in the 28 low mantissa bits the f32 does not have (|change| < half an f32 ulp)
+__device__ __forceinline__ double dither64(float v, uint32_t h) {
+    const double x = (double)v;
+    return __hiloint2double(__double2hiint(x), __double2loint(x) ^ (int)(h & 0x0FFFFFFFu));
 }
-// raytrace.rs:40-42: origin + direction * t, two roundings
-__device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {
-#pragma clang fp contract(off)
-    return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+__device__ __forceinline__ d3 dither64(f3 v, uint32_t& h) {
+    d3 r;
+    h = pcg_hash(h); r.x = dither64(v.x, h);
+    h = pcg_hash(h); r.y = dither64(v.y, h);
+    h = pcg_hash(h); r.z = dither64(v.z, h);
+    return r;
 }
 
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
@@ -393,8 +413,8 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     if (take) {
                         ray = cand;
                         // A refill is a chain of dependent memory round trips during which the wave's other
-                        // lanes wait, so it is kept to two: (ray words a and b) -> (record of the primitive
-                        // the ray starts on).  Planes and big spheres come from LDS.
+                        // lanes wait, so it is kept to one: the ray words a and b.  Planes and big spheres come
+                        // from LDS; whether the ray re-hits the triangle it starts on was decided by k_shade.
                         float4 A = q.a[ray], B;
                         if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                             B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
@@ -405,21 +425,15 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         src = __float_as_uint(B.z);
                         if (src == SRC_INVALID) {
                             hits[ray] = make_float2(-1.f, __uint_as_float(HIT_INVALID));   // padding slot
+                        } else if ((src >> 30) == 1u) {
+                            // the ray re-hits the triangle it starts on at t ~ 1e-16 (k_shade's verdict, see tri_hit_ref):
+                            // nothing can be closer, no traversal
+                            hits[ray] = make_float2(0.f, __uint_as_float(src & SRC_PRIM_MASK));
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
                             best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu;
-                            // a ray that starts on a triangle tests that triangle with the reference's own
-                            // operation sequence (see tri_hit_ref); the traversal below skips it
-                            if (src < sc.n_leaf_prims) {
-                                const float4* __restrict__ sp_ = prims + 3 * (size_t)src;
-                                const float4 s0 = sp_[0], s1 = sp_[1], s2 = sp_[2];
-                                if (__float_as_uint(s2.z) == PRIM_TRIANGLE) {
-                                    float t, a, b;
-                                    if (COUNT) cnt_prims++;
-                                    if (tri_hit_ref(o, d, mk(s0.x, s0.y, s0.z), mk(s0.w, s1.x, s1.y), mk(s1.z, s1.w, s2.x), t, a, b))
-                                        consider(best, t, src, __float_as_uint(s2.y));
-                                }
-                            }
+                            // (a ray that starts on a triangle does not hit it again -- k_shade has decided that -- and the
+                            // traversal below skips it)
                             // (the pointer is laundered so that the reads stay here: hoisted out of the loop
                             // they would occupy 80 registers for the whole kernel)
                             typedef __attribute__((address_space(3))) v4f lds_f4;
@@ -691,7 +705,7 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 #define RT_SHADE_THREADS 1024
 #endif
 #ifndef RT_SHADE_MINWAVES
-#define RT_SHADE_MINWAVES 8   // <= 64 VGPRs: two 1024-thread blocks per CU, one computes while the other waits at its barriers
+#define RT_SHADE_MINWAVES 4   // (the f64 hit-point / self-intersection arithmetic needs ~90 VGPRs)
 #endif
 #ifndef RT_SHADE_GRID_MUL
 #define RT_SHADE_GRID_MUL 2u
@@ -729,12 +743,15 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {   // block-uniform trip count
         bool emit = false;       // continue with a scattered ray
         bool fire = false;       // spawn shadow rays
+        bool on_tri = false;     // the hit is on a triangle: p64 is its f64 hit point
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
-        uint32_t rng = 0, pid = 0, code = HIT_MISS;
+        d3 p64 = mkd(0, 0, 0);
+        uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
         if (i < n) {
             const float4 A = qi.a[i];
             const float2 H = hits[i];
             f3 o, d;
+            uint32_t src = SRC_NONE;
             if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                 o = mk(sc.eye[0], sc.eye[1], sc.eye[2]); d = mk(A.x, A.y, A.z);
                 pid = i;
@@ -743,6 +760,7 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
             } else {
                 const float4 B = qi.b[i], C = qi.c[i];
                 o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
+                src = __float_as_uint(B.z);
                 pid = __float_as_uint(B.w);
                 thr = mk(C.x, C.y, C.z);
                 rng = __float_as_uint(C.w);
@@ -763,26 +781,37 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                     mat = __float_as_int(P1.w);
                     p = at_ref(o, d, t);                                                   // raytrace.rs:40-42
                 } else {
-                    // one 64-byte shading record per primitive: a single cache line per gather
-                    const float4* __restrict__ rec = sc.smeta + 4 * (size_t)code;
-                    const float4 S = rec[0], r0 = rec[1], r1 = rec[2], r2 = rec[3];
+                    // one 96-byte shading record per primitive
+                    const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)code;
+                    const float4 S = rec[0];
                     const uint32_t sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
                     if (!(sw & SMETA_SPHERE)) {
-                        const f3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
-                        // hit point from the reference's own t sequence (see tri_hit_ref)
-                        t = tri_t_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2);
-                        p = at_ref(o, d, t);                                               // intersections.rs:172
+                        // t, the hit point and the barycentrics with the reference's own f64 sequence on its own f64
+                        // operands (see tri_hit_ref).  The ray enters it as f64: the exact eye for a primary ray, the
+                        // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
+                        const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
+                        const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                        dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
+                        d3 o64;
+                        if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
+                        else if ((src >> 30) == 1u) { const double2 e0 = qi.e[2 * (size_t)i], e1 = qi.e[2 * (size_t)i + 1]; o64 = mkd(e0.x, e0.y, e1.x); }
+                        else o64 = dither64(o, dh);
+                        const d3 d64 = dither64(d, dh);
+                        double t0, a, b;
+                        tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
+                        p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
+                        p = mk((float)p64.x, (float)p64.y, (float)p64.z);
+                        on_tri = true;
                         if (sw & SMETA_HAS_UV) {                                           // intersections.rs:177-183
                             const float* uv = sc.uvs + 6 * (size_t)sc.meta[code].w;
-                            float a, b;
-                            tri_ab_ref(o, d, mk(r0.x, r0.y, r0.z), e1, e2, a, b);          // intersections.rs:159-160
-                            const float c = 1.f - a - b;
-                            u = a * uv[2] + b * uv[4] + c * uv[0];
-                            v = a * uv[3] + b * uv[5] + c * uv[1];
+                            const double c = 1.0 - a - b;
+                            u = (float)(a * (double)uv[2] + b * (double)uv[4] + c * (double)uv[0]);
+                            v = (float)(a * (double)uv[3] + b * (double)uv[5] + c * (double)uv[1]);
                         }
                     } else {
+                        const float4 r0 = rec[1], r1 = rec[2];
                         p = at_ref(o, d, t);                                               // intersections.rs:68
                         nrm = sphere_normal(r0, r1, o, d, t);                              // intersections.rs:69
                     }
@@ -841,14 +870,30 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                 }
             }
         }
+        // A ray that leaves a triangle: does it re-hit that triangle at t ~ 0?  (intersections.rs:166 has no epsilon;
+        // see tri_hit_ref.)  The reference's f64 test on the f64 hit point; the verdict travels in the src word.
+        auto leaves_src = [&](f3 dir_out, uint32_t& src_out) -> bool {
+            src_out = code;
+            if (!on_tri) return false;
+            const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
+            const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
+            const d3 nd64 = dither64(dir_out, dh);
+            double t1, a1, b1;
+            if (!tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1)) return false;
+            src_out = code | SRC_SELF_BIT;
+            return true;
+        };
         if (!last) {
             // (ordering the block's slots by the octant of the new direction was measured: no gain)
             const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (emit) {
                 if (slot < capacity) {
+                    uint32_t src_out;
+                    const bool self = leaves_src(ndir, src_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
-                    qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(code), __uint_as_float(pid));
+                    qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
+                    if (self) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -862,9 +907,12 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                     if (slot >= capacity) { atomicAdd(&ctl[CTL_OVERFLOW], 1u); continue; }
                     const float4 Lp = sc.lights[l];
                     const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
+                    uint32_t src_out;
+                    const bool self = leaves_src(sd, src_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
-                    qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(code), __uint_as_float(pid));
+                    qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pcg_hash(rng + 0x9E3779B9u * (l + 1u))));
+                    if (self) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
                 }
             }
         }
@@ -950,8 +998,17 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
             const int4 M = sc.meta[code];
             o = M.x; t = M.y;
             if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
-                const float4 S = sc.smeta[4 * (size_t)code];
+                const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)code;
+                const float4 S = rec[0];
                 nrm = mk(S.x, S.y, S.z);
+                // the distance k_shade works with: the reference's f64 sequence on this very ray (the traversal's f32 t only
+                // ranks the candidates; on a grazing hit it is good to 1e-4, not 1e-5)
+                const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
+                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                double t0, a, b;
+                tri_hit_ref(mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]), mkd((double)A.w, (double)B.x, (double)B.y), mkd(w0.x, w0.y, w1.x),
+                            mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
+                tt = (float)t0;
             } else {
                 nrm = sphere_normal(r0, r1, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), tt);
             }

@@ -140,9 +140,12 @@ def test_resolve_colour_plane(ctx):
     assert (rgb8.cpu().numpy() != bytes_want).mean() < 1e-3                    # f32 product at an integer boundary
     # NaN and negative sums: f64::min(NaN, 1.0) == 1.0 and `as u8` saturates (image.rs:37-43)
     acc.zero_()
+    # (sqrt of a negative sum is NaN as well, so it ends at 1.0 too: raytrace.rs:146-149 has no lower clamp)
     acc[0, 0, 0], acc[0, 0, 1], acc[0, 0, 2] = float("nan"), -1.0, 1e30
+    acc[0, 1, 0], acc[0, 1, 1], acc[0, 1, 2] = 0.0, 0.25, 1.0
     rgb8, color = ctx.resolve(acc, 1, want_color=True)
-    assert rgb8[0, 0].tolist() == [255, 0, 255] and color[0, 0, 0].item() == 1.0 and np.isnan(color[0, 0, 1].item())
+    assert rgb8[0, 0].tolist() == [255, 255, 255] and color[0, 0].tolist() == [1.0, 1.0, 1.0]
+    assert rgb8[0, 1].tolist() == [0, 127, 255] and color[0, 1].tolist() == [0.0, 0.5, 1.0]
 
 
 def test_cli_binary_end_to_end(ctx, tmp_path):

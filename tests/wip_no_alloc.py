@@ -30,7 +30,7 @@ def test_noalloc_matches_the_allocating_entry_point_twice():
     import os
     ctx = rt.Context(0)
     try:
-        # first call: 485 spheres + 6,400 triangles at 240x136, 8 samples (261,120 paths, no lights: deterministic)
+        # first call: 485 spheres + 6,400 triangles at 240x136, 8 samples (261,120 paths = 48 MB of state, no lights: deterministic)
         sc = scenegen.scene_c5(width=240, height=136, nu=80, nv=40)
         ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
         p1 = rt.RenderParams("jitter:4", depth=5, seed=3, sample_begin=2, sample_end=10)
@@ -59,19 +59,19 @@ def test_noalloc_limits_are_errors():
         sc = scenegen.scene_c3(width=640, height=360)
         ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
         acc = torch.zeros((ctx.height, ctx.width, 3), dtype=torch.float32, device="cuda:0")
-        # 640x360 = 230,400 paths per sample: two samples fit the 64 MiB scratch (120 B per path), three do not
-        ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=2), acc)
+        # 640x360 = 230,400 paths per sample: one sample fits the 64 MiB scratch (184 B per path), two do not
+        ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=1), acc)
         with pytest.raises(rt.RtError, match="static scratch"):
-            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=3), acc)
+            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=2), acc)
         with pytest.raises(rt.RtError, match="ONE pass"):
-            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=2, max_paths_per_pass=64 * 100), acc)
+            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=1, max_paths_per_pass=64 * 100), acc)
         with pytest.raises(rt.RtError, match="TIMING"):
             ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=1, timing=True), acc)
         torch.cuda.synchronize()
-        # the whole frame in two calls of two samples each equals the allocating call over all four
+        # the whole frame in four calls of one sample each equals the allocating call over all four
         acc.zero_()
-        for s0 in (0, 2):
-            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, seed=2, sample_begin=s0, sample_end=s0 + 2), acc)
+        for s0 in range(4):
+            ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, seed=2, sample_begin=s0, sample_end=s0 + 1), acc)
         ref = torch.zeros_like(acc)
         ctx.render_accumulate(rt.RenderParams("jitter:2", depth=3, seed=2), ref)
         torch.cuda.synchronize()
