@@ -4,17 +4,19 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL = backend "nccl")
 
-Workload (BASELINE.json): the combined scene of config C5 -- ~485 RTIOW spheres + the
-1,000,000-triangle torus -- at 1920x1080, depth 5, jittered 64x64 sample grid.  One STEP =
-one pass of the hot path over one batch: `--spp-per-step` (default 64) samples per pixel
-of the full frame on every rank (a disjoint cell range of the 64x64 grid per rank and step:
-the C5 "sample split"), followed by the RCCL sum-reduce of the f32 accumulators to rank 0
-and the resolve there.  Per-GPU work is fixed as N grows => weak scaling.  `--workload c3`
-(spheres only) and `--workload c4` (torus + plane at 3840x2160, tile split with
-`--split tiles`) are available for the other configs.
+Workload (BASELINE.json): the combined scene of config C5 -- ~485 RTIOW spheres + the 1,000,000-triangle torus -- at
+1920x1080, depth 5, jittered 64x64 sample grid.  One STEP = one pass of the hot path over one batch:
+`--spp-per-step` (default 64) samples per pixel of the full frame on every rank (a disjoint cell range of the 64x64
+grid per rank and step: the C5 "sample split"), followed by the RCCL sum-reduce of the f32 accumulators to rank 0 and
+the resolve there.  Per-GPU work is fixed as N grows => weak scaling.  `--split tiles` deals the 8x8 tiles of ONE frame
+to the ranks instead (fixed total work => strong scaling; the C4 configuration).  At N = 1 the same JSON line also
+carries C3 (spheres only, 1080p) and C4 (torus + plane, 3840x2160) under "other_workloads".
 
-value = rays actually traced by all ranks (primary + scattered + shadow) / wall time.
-Rays are counted on the device by the queue counters (rt_get_stats).
+value = rays actually traced by all ranks (primary + scattered + shadow) / wall time.  Rays are counted on the device
+by the queue counters (rt_get_stats).
+
+  python bench.py --render OUT.png     the north-star artefact: C5 at 1920x1080, 1024 spp (jitter:32), through
+                                       rt_render_image; writes the PNG and prints a JSON line with time-to-image
 """
 import argparse
 import importlib
@@ -27,60 +29,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+# MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0        # aggregate L2 bandwidth
+VALU_PEAK_TFLOPS = 157.3     # peak FP32 vector
+N_SIMD = 1024                # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4
+VALU_PIPE_PEAK_GCYC = N_SIMD * CLOCK_GHZ     # VALU pipe cycles available per second, in 1e9
+
+WORKLOADS = {
+    "c3": ("C3 RTIOW ~485 spheres", "Mrays/s (whole node) at 1080p"),
+    "c4": ("C4 1M-triangle torus + plane", "Mrays/s (whole node) at 4K"),
+    "c5": ("C5 ~485 spheres + 1M-triangle torus", "Mrays/s (whole node) at 1080p"),
+}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c5", choices=["c3", "c4", "c5"])
-    ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--depth", type=int, default=5)
-    ap.add_argument("--split", default=None, choices=["spp", "tiles"])
-    ap.add_argument("--paths-per-pass", type=int, default=0, help="rt_render_params.max_paths_per_pass (0 = library default)")
-    ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="BVH builder: host binned SAH (default) or GPU linear BVH")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-step", type=int, default=6, help="cpu_baseline traces every n-th pixel and row")
-    ap.add_argument("--small", action="store_true", help="tiny configuration for plumbing checks (not a valid measurement)")
-    args = ap.parse_args()
+def make_scene(scenegen, workload, small):
+    if workload == "c3":
+        return scenegen.scene_c3(*((320, 180) if small else (1920, 1080)))
+    if workload == "c4":
+        return scenegen.scene_c4(*((384, 216, 100, 50) if small else (3840, 2160, 1000, 500)))
+    return scenegen.scene_c5(*((320, 180, 100, 50) if small else (1920, 1080, 1000, 500)))
 
-    import numpy as np
+
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def isa_model(cst, launches):
+    """VALU pipe cycles per closest-hit launch from the committed ISA histogram (tools/isa_histogram.py) times what the
+    counters build saw the waves do: `always` counts only the straight-line part of each region (a lower bound), `total`
+    every instruction of the region (an upper bound).  The PMC-measured figure lies between the two."""
+    h = load_json("r02_isa_closest_hit.json")
+    if not h or not cst.get("wave_node_steps"):
+        return None
+    r = h["regions"]
+    steps = {"node": cst["wave_node_steps"], "leaf": cst["wave_leaf_steps"], "refill": cst["wave_refills"]}
+
+    def cyc(which):
+        g = lambda name: r.get(name, {}).get("valu_cycles_" + which, 0)
+        leaf = g("leaf") + g("leaf_end") + (g("leaf_tri") + g("leaf_sphere") if which == "total" else min(g("leaf_tri"), g("leaf_sphere")))
+        refill = g("refill") + g("refill_take")
+        ctl = g("control")
+        return (steps["node"] * (g("node") + ctl) + steps["leaf"] * (leaf + ctl) + steps["refill"] * refill) / max(1, launches)
+
+    return {"valu_pipe_cycles_per_launch_lower": cyc("always"), "valu_pipe_cycles_per_launch_upper": cyc("total"),
+            "wave_node_steps_per_launch": steps["node"] / max(1, launches), "wave_leaf_steps_per_launch": steps["leaf"] / max(1, launches),
+            "wave_refills_per_launch": steps["refill"] / max(1, launches), "source": "profiles/r02_isa_closest_hit.json x rt_get_stats counters"}
+
+
+def run_workload(rt, scenegen, args, workload, rank, world, dev, steps, warmup, split):
+    """Warm-up, one counters step, then `steps` timed steps of `workload`; returns the result dict (rank 0) or None."""
     import torch
     import torch.distributed as dist
+    D = importlib.import_module("raytracer-rust_amd.distributed")
 
-    rt = importlib.import_module("raytracer-rust_amd")
-    scenegen = importlib.import_module("raytracer-rust_amd.scenegen")
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    # ---------------------------------------------------------------- scene
-    split = args.split or ("tiles" if args.workload == "c4" else "spp")
-    if args.workload == "c3":
-        sc = scenegen.scene_c3(*((320, 180) if args.small else (1920, 1080)))
-        name = "C3 RTIOW ~485 spheres"
-    elif args.workload == "c4":
-        sc = scenegen.scene_c4(*((384, 216, 100, 50) if args.small else (3840, 2160, 1000, 500)))
-        name = "C4 1M-triangle torus + plane"
-    else:
-        sc = scenegen.scene_c5(*((320, 180, 100, 50) if args.small else (1920, 1080, 1000, 500)))
-        name = "C5 ~485 spheres + 1M-triangle torus"
+    sc = make_scene(scenegen, workload, args.small)
     W, H = sc["width"], sc["height"]
     grid_n = 64                                   # jitter:64 -> 4096 cells, SURVEY 8d C5
     spp = args.spp_per_step
     t0 = time.time()
     scene = rt.Scene.from_objects(W, H, sc["background"], sc["camera"], sc["objects"])
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(dev.index)
     ctx.set_bvh_builder(args.bvh)
     ctx.upload(scene)
     upload_s = time.time() - t0
@@ -91,15 +104,9 @@ def main():
 
     def step(k, timing=False, counters=False):
         """One batch: spp samples/pixel on this rank (or this rank's tiles), reduce, resolve."""
-        if split == "spp":
-            cell0 = ((k * world + rank) * spp) % (grid_n * grid_n)      # disjoint cell ranges per rank and step
-            p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
-                                sample_end=cell0 + spp, timing=timing, counters=counters, max_paths_per_pass=args.paths_per_pass)
-        else:
-            cell0 = (k * spp) % (grid_n * grid_n)
-            p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=cell0,
-                                sample_end=cell0 + spp, tile_index=rank, tile_count=world, timing=timing, counters=counters,
-                                max_paths_per_pass=args.paths_per_pass)
+        sb, se, ti, tc = D.bench_step_params(k, rank, world, spp, grid_n, split)
+        p = rt.RenderParams(rt.SuperSampling("Jitter", grid_n), depth=args.depth, seed=1234, sample_begin=sb, sample_end=se,
+                            tile_index=ti, tile_count=tc, timing=timing, counters=counters, max_paths_per_pass=args.paths_per_pass)
         accum.zero_()
         ctx.render_accumulate(p, accum, stream.cuda_stream)
         if world > 1:
@@ -121,22 +128,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     # ---------------------------------------------------------------- warmup, counters
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
     barrier()
     ctx.stats_reset()
-    step(0, counters=True)                                            # untimed: mean nodes / prims per ray
+    step(0, counters=True)                                            # untimed: what the rays and the waves do
     cst = ctx.stats()
     nodes_per_ray = cst["nodes_visited"] / max(1, cst["rays_total"])
     prims_per_ray = cst["prims_tested"] / max(1, cst["rays_total"])
+    counter_launches = len([x for x in cst["rays_per_iteration"] if x > 0])
     barrier()
     ctx.stats_reset()
 
     # ---------------------------------------------------------------- timed region
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, timing=True)
+    for k in range(steps):
+        step(warmup + k, timing=True)
     barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
@@ -148,67 +156,183 @@ def main():
     elapsed = float(t_el.item())
     total_rays, total_paths = float(rays[0].item()), float(rays[1].item())
 
+    out = None
     if rank == 0:
+        import numpy as np
+        name, metric = WORKLOADS[workload]
         n_planes = len([o for o in sc["objects"] if o["type"] == "Plane"])
-        # algorithmic bytes of one closest-hit query ("k_closest_hit"): 32 B ray words a,b in (16 B for a primary ray),
-        # 8 B hit record out, 64 B per BVH node visited, 48 B per primitive tested, 32 B per plane
-        r0 = float(st["rays_per_iteration"][0]) / max(1.0, float(st["rays_total"]))     # primary rays are 16 B, the others 32 B (a, b)
+        mesh_objects = [i for i, o in enumerate(sc["objects"]) if o["type"] == "Mesh"]
+        hits = ctx.primary_hits(0.5, 0.5)
+        mesh_share = float(np.isin(hits["object_id"], mesh_objects).mean()) if mesh_objects else 0.0
+        # algorithmic bytes of one closest-hit query ("k_closest_hit"): 32 B ray words a,b in (16 B for a primary
+        # ray), 8 B hit record out, 64 B per BVH node visited, 48 B per primitive tested, 32 B per plane
+        r0 = float(st["rays_per_iteration"][0]) / max(1.0, float(st["rays_total"]))
         bytes_per_ray = (16.0 * r0 + 32.0 * (1.0 - r0)) + 8.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray + 32.0 * n_planes
         flops_per_ray = 40.0 * nodes_per_ray + 45.0 * prims_per_ray + 10.0 * n_planes
         launches = max(1, st["hit_launches"])
         rays_per_launch = st["rays_total"] / launches
         ms_per_launch = st["hit_ms"] / launches
-        achieved = rays_per_launch * bytes_per_ray / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        valu = rays_per_launch * flops_per_ray / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
-        traffic = None
-        valu_busy = None
-        valu_pipe = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc runs)
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and not args.small:
-                    traffic = tj.get("bytes_per_launch")
-                    valu_busy = tj.get("valu_issue_busy")
-                    valu_pipe = tj.get("valu_pipe_busy")
-            except Exception:
-                traffic = None
+        sec = ms_per_launch * 1e-3
+        request_rate = rays_per_launch * bytes_per_ray / sec / 1e9 if sec > 0 else 0.0
+        valu_tflops = rays_per_launch * flops_per_ray / sec / 1e12 if sec > 0 else 0.0
+        # PMC figures of the same command (separate rocprofv3 --pmc passes, tools/pmc_profile.sh -> profiles/r02_pmc.json),
+        # stored per ray so that they scale with the live ray count of this run
+        pmc = (load_json("r02_pmc.json") or {}).get(workload) if not args.small else None
+        model = isa_model(cst, counter_launches)
+        roof = {"bound": "valu_issue", "kernel": "k_closest_hit", "unit": "G VALU-pipe-cycles/s", "peak": VALU_PIPE_PEAK_GCYC,
+                "achieved": None, "frac": None, "traffic": None,
+                "launches": st["hit_launches"], "ms_per_launch": ms_per_launch, "rays_per_launch": rays_per_launch,
+                "nodes_per_ray": nodes_per_ray, "prims_per_ray": prims_per_ray,
+                "self_hit_rays_share": cst["self_hit_rays"] / max(1, cst["rays_total"]),
+                "lanes_with_work_per_step": cst["step_lanes"] / max(1, 64 * (cst["wave_node_steps"] + cst["wave_leaf_steps"])),
+                "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
+                "rays_per_iteration_per_step": [x / steps for x in st["rays_per_iteration"][:8]],
+                "isa_model": model}
+        if pmc and sec > 0:
+            cyc = pmc["valu_pipe_cycles_per_ray"] * rays_per_launch
+            roof["achieved"] = cyc / sec / 1e9
+            roof["frac"] = roof["achieved"] / VALU_PIPE_PEAK_GCYC
+            roof["traffic"] = pmc["fetch_write_bytes_per_ray"] * rays_per_launch
+            roof["valu_insts_per_ray_pmc"] = pmc["valu_insts_per_ray"]
+            roof["lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
+            roof["wave_time_split_pmc"] = pmc.get("wave_time_split")
+            roof["hbm"] = {"bound": "hbm", "achieved": roof["traffic"] / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": roof["traffic"] / sec / 1e9 / HBM_PEAK_GBS,
+                           "note": "FETCH_SIZE + WRITE_SIZE: L2-miss traffic, Infinity Cache hits included (MI355X_MICROARCH.md), "
+                                   "so an upper bound of the HBM bytes"}
+        elif model and sec > 0:
+            # no PMC file for this workload: the ISA-histogram lower bound (still cannot exceed 1)
+            roof["achieved"] = model["valu_pipe_cycles_per_launch_lower"] * (rays_per_launch / max(1.0, cst["rays_total"] / max(1, counter_launches))) / sec / 1e9
+            roof["frac"] = roof["achieved"] / VALU_PIPE_PEAK_GCYC
+        roof["l2_request_rate"] = {"achieved": request_rate, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": request_rate / L2_PEAK_GBS,
+                                   "bytes_per_ray": bytes_per_ray,
+                                   "note": "algorithmic bytes (DESIGN.md section 4) / launch time: a request rate served by L1/L2/Infinity "
+                                           "Cache, priced against the aggregate L2 bandwidth -- not HBM traffic"}
+        roof["valu_flop_model"] = {"tflops": valu_tflops, "frac": valu_tflops / VALU_PEAK_TFLOPS,
+                                   "note": "SURVEY 8d flop model (40/node, 45/primitive): counts the arithmetic of the tests only, "
+                                           "about a tenth of the VALU instructions issued"}
+        roof["note"] = ("k_closest_hit is bound by VALU issue and latency: frac = VALU pipe cycles issued (2 per wave64 instruction, "
+                        "4 for f64 and transcendental; SQ_INSTS_VALU* of the same command, profiles/r02_pmc.json) / (1024 SIMDs x "
+                        "launch time x 2.4 GHz); the scene is served by the caches, HBM-side traffic is `hbm`")
         out = {
-            "metric": "Mrays/s (whole node) at 1080p" if args.workload != "c4" else "Mrays/s (whole node) at 4K",
-            "value": total_rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": metric, "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak" if split == "spp" else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %dx%d, depth %d, %d spp/step/GPU of a jitter:%d grid, %s split%s" %
-                                   (name, W, H, args.depth, spp, grid_n, split, " [SMALL: not a measurement]" if args.small else ""),
-                       "paths_per_step": total_paths / args.steps, "rays_per_path": total_rays / max(1.0, total_paths),
-                       "samples_per_s": total_paths / elapsed, "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"],
+            "config": {"workload": "%s, %dx%d, depth %d, %d spp/step%s of a jitter:%d grid, %s split%s" %
+                                   (name, W, H, args.depth, spp, "/GPU" if split == "spp" else "", grid_n, split,
+                                    " [SMALL: not a measurement]" if args.small else ""),
+                       "paths_per_step": total_paths / steps, "rays_per_path": total_rays / max(1.0, total_paths),
+                       "samples_per_s": total_paths / elapsed, "mesh_share_of_primary_hits": mesh_share,
+                       "mesh_winding": "outward (lit torus)", "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"],
                        "bvh_build_ms": st["bvh_build_ms"], "bvh_builder": args.bvh, "scene_upload_s": upload_s},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_closest_hit", "launches": st["hit_launches"], "ms_per_launch": ms_per_launch,
-                         "rays_per_launch": rays_per_launch, "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray,
-                         "prims_per_ray": prims_per_ray, "hit_kernel_share_of_step": st["hit_ms"] * 1e-3 / elapsed,
-                         "valu_tflops": valu, "valu_frac": valu / VALU_PEAK_TFLOPS, "valu_issue_busy_pmc": valu_busy, "valu_pipe_busy_pmc": valu_pipe,
-                         "rays_per_iteration_per_step": [x / args.steps for x in st["rays_per_iteration"][:8]],
-                         "note": "achieved = algorithmic bytes (DESIGN.md section 4) / launch time; the 83 MB scene is served by L1/L2/"
-                                 "Infinity Cache (traffic = HBM-side bytes per launch from the PMC passes is ~15% of the algorithmic "
-                                 "bytes), so frac near or above 1 means HBM is not the limiter: the kernel is bound by latency and "
-                                 "instruction issue (VALU pipes 59% busy, waves 46% of their time at s_waitcnt; profiles/traffic.json)"},
+            "roofline": roof,
         }
+    ctx.close()
+    del accum, total
+    torch.cuda.empty_cache()
+    return out, sc
+
+
+def render_north_star(rt, scenegen, out_png=None, n=32, depth=5, seed=2026, device=0, small=False):
+    """BASELINE.json's target artefact: C5 at 1920x1080, n*n = 1024 spp, through rt_render_image (host outputs).
+    Returns (accum (H,W,3) float32 sample sums, rgb8, info dict).  No oracle here: the gate on this very frame is
+    tests/test_gpu_northstar.py, which calls this function."""
+    sc = make_scene(scenegen, "c5", small)
+    t0 = time.perf_counter()
+    scene = rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"])
+    ctx = rt.Context(device)
+    ctx.upload(scene)
+    t_upload = time.perf_counter() - t0
+    ctx.render_image(rt.RenderParams("jitter:1", depth=depth, seed=seed))         # first-launch costs (code objects) are not the image's
+    ctx.stats_reset()
+    t1 = time.perf_counter()
+    acc, rgb = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=depth, seed=seed))
+    t_render = time.perf_counter() - t1
+    st = ctx.stats()
+    t2 = time.perf_counter()
+    if out_png:
+        rt.write_png(out_png, rgb)
+    t_png = time.perf_counter() - t2
+    info = {"artefact": "C5 (%d spheres + 1,000,000-triangle torus), %dx%d, %d spp (jitter:%d), depth %d" %
+                        (len([o for o in sc["objects"] if o["type"] == "Sphere"]), sc["width"], sc["height"], n * n, n, depth),
+            "time_to_image_s": t_render, "scene_upload_s": t_upload, "png_write_s": t_png, "rays": st["rays_total"], "paths": st["paths"],
+            "mrays_per_s": st["rays_total"] / t_render / 1e6, "msamples_per_s": st["paths"] / t_render / 1e6,
+            "note": "time_to_image = rt_render_image wall time: all passes, resolve and the copies of the f32 sums (24.9 MB) and the "
+                    "RGB8 frame (6.2 MB) to the host", "png": out_png}
+    ctx.close()
+    return acc, rgb, sc, info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c5", choices=["c3", "c4", "c5"])
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--split", default=None, choices=["spp", "tiles"])
+    ap.add_argument("--paths-per-pass", type=int, default=0, help="rt_render_params.max_paths_per_pass (0 = library default)")
+    ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="BVH builder: host binned SAH (default) or GPU linear BVH")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 legs of the N = 1 line")
+    ap.add_argument("--cpu-sample-step", type=int, default=5, help="cpu_baseline traces every n-th pixel and row")
+    ap.add_argument("--small", action="store_true", help="tiny configuration for plumbing checks (not a valid measurement)")
+    ap.add_argument("--render", default=None, metavar="OUT.png", help="render the north-star frame instead of benchmarking")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rt = importlib.import_module("raytracer-rust_amd")
+    scenegen = importlib.import_module("raytracer-rust_amd.scenegen")
+
+    if args.render:
+        _, _, _, info = render_north_star(rt, scenegen, args.render, small=args.small)
+        print(json.dumps(info), flush=True)
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    split = args.split or ("tiles" if args.workload == "c4" else "spp")
+    out, sc = run_workload(rt, scenegen, args, args.workload, rank, world, dev, args.steps, args.warmup, split)
+    if rank == 0:
+        if world == 1 and not args.no_other_workloads:
+            # the other two BASELINE configurations, driver-timed in the same run (fewer steps: they are context, not the headline)
+            others = {}
+            for w in ("c3", "c4"):
+                if w == args.workload:
+                    continue
+                o, _ = run_workload(rt, scenegen, args, w, 0, 1, dev, max(2, args.steps // 2), 1, "tiles" if w == "c4" else "spp")
+                r = o["roofline"]
+                others[w] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                             "steps": o["steps"], "samples_per_s": o["config"]["samples_per_s"], "rays_per_path": o["config"]["rays_per_path"],
+                             "mesh_share_of_primary_hits": o["config"]["mesh_share_of_primary_hits"],
+                             "closest_hit_ms_per_launch": r["ms_per_launch"], "rays_per_launch": r["rays_per_launch"],
+                             "nodes_per_ray": r["nodes_per_ray"], "prims_per_ray": r["prims_per_ray"],
+                             "roofline_frac": r["frac"], "hit_kernel_share_of_step": r["hit_kernel_share_of_step"]}
+            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scenegen, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 def cpu_baseline(sc, scenegen, args):
     """The oracle (the reference's own algorithm: linear object scan, brute-force triangles behind
-    one AABB, f64) timed on this box's host cores on a bounded sample of the same workload."""
+    one AABB, f64; its optional cull stays OFF) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle_py as O
     threads = min(os.cpu_count() or 1, 16)        # the GPU box grants 16 cores per GPU
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))

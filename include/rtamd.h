@@ -135,6 +135,12 @@ typedef struct rt_stats {
     double hit_ms;                             /* RT_FLAG_TIMING: sum of their durations     */
     uint32_t bvh_nodes, bvh_depth, bvh_prims;
     double bvh_build_ms;
+    /* RT_FLAG_COUNTERS only: what the closest-hit WAVES did (the roofline model of bench.py is built on these) */
+    uint64_t wave_node_steps;                  /* steps in which a wave ran the BVH-node code                */
+    uint64_t wave_leaf_steps;                  /* steps in which a wave ran the primitive code               */
+    uint64_t wave_refills;                     /* times a wave fetched new rays into idle lanes              */
+    uint64_t self_hit_rays;                    /* rays that re-hit the triangle they start on (no traversal) */
+    uint64_t step_lanes;                       /* lanes that had work, summed over all steps                 */
 } rt_stats;
 
 /* No reference counterpart (the reference is single-process CPU code). */

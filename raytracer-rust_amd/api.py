@@ -338,7 +338,8 @@ class Context:
         return dict(rays_total=int(s.rays_total), rays_per_iteration=per, paths=int(s.paths), nodes_visited=int(s.nodes_visited),
                     prims_tested=int(s.prims_tested), queue_overflow=int(s.queue_overflow), hit_launches=int(s.hit_launches),
                     hit_ms=float(s.hit_ms), bvh_nodes=int(s.bvh_nodes), bvh_depth=int(s.bvh_depth), bvh_prims=int(s.bvh_prims),
-                    bvh_build_ms=float(s.bvh_build_ms))
+                    bvh_build_ms=float(s.bvh_build_ms), wave_node_steps=int(s.wave_node_steps), wave_leaf_steps=int(s.wave_leaf_steps),
+                    wave_refills=int(s.wave_refills), self_hit_rays=int(s.self_hit_rays), step_lanes=int(s.step_lanes))
 
     def stats_reset(self):
         self._check(self._L.rt_stats_reset(self._h))

@@ -58,7 +58,7 @@ struct rt_context {
     float2* hits = nullptr;    // (t, code) per ray
     float4* radiance = nullptr;
     uint32_t* ctl = nullptr;
-    unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 3 words
+    unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 1 + N_STAT64 words
     uint64_t paths_total = 0;
     uint64_t rays0_total = 0;   // primary rays actually traced (iteration 0)
 
@@ -196,8 +196,8 @@ int rt_context_create(int device_id, rt_context** out) {
     if (e != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); }
     // control block and statistics live as long as the context (no entry point allocates them later)
     e = hipMalloc((void**)&ctx->ctl, CTL_WORDS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->stats_dev, (CTL_MAX_IT + 3) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 3) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->stats_dev, (CTL_MAX_IT + 1 + N_STAT64) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 1 + N_STAT64) * sizeof(unsigned long long));
     if (e != hipSuccess) { rt_context_destroy(ctx); return fail(nullptr, "hipMalloc: %s", hipGetErrorString(e)); }
     {   // device address of the no-alloc scratch array, once per device, with that device current
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -238,7 +238,7 @@ struct FlatScene {
     std::vector<float> uvs;
     std::vector<int32_t> plane_obj;
     std::vector<uchar4> texels;
-    uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0;
+    uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0, n_tris = 0;
     float bg[3], eye[3];
     double eye64[3], lle[3], hz[3], vt[3];
     uint32_t width = 0, height = 0, stack_depth = 2, bvh_depth = 0;
@@ -444,6 +444,7 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
     f.n_leaf_prims = n_leaf_prims;
     f.n_nodes = (uint32_t)bvh.nodes.size();
     f.n_planes = d->n_planes;
+    f.n_tris = (uint32_t)d->n_triangles;
     f.n_lights = d->n_lights;
     for (int k = 0; k < 3; ++k) {
         f.bg[k] = (float)d->background[k];
@@ -477,6 +478,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     sc.n_leaf_prims = f.n_leaf_prims;
     sc.n_nodes = f.n_nodes;
     sc.n_planes = f.n_planes;
+    sc.n_tris = f.n_tris;
     sc.n_lights = f.n_lights;
     for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.eye64[k] = f.eye64[k]; sc.lle[k] = f.lle[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
     sc.width = f.width; sc.height = f.height;
@@ -969,13 +971,18 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (ctx->stats_dev) {
-        std::vector<unsigned long long> h(CTL_MAX_IT + 3);
+        std::vector<unsigned long long> h(CTL_MAX_IT + 1 + N_STAT64);
         HIP_TRY(ctx, hipMemcpy(h.data(), ctx->stats_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         h[0] = ctx->rays0_total;
         for (int i = 0; i < CTL_MAX_IT; ++i) { out->rays_per_iteration[i] = h[i]; out->rays_total += h[i]; }
         out->queue_overflow = h[CTL_MAX_IT];
         out->nodes_visited = h[CTL_MAX_IT + 1];
         out->prims_tested = h[CTL_MAX_IT + 2];
+        out->wave_node_steps = h[CTL_MAX_IT + 3];
+        out->wave_leaf_steps = h[CTL_MAX_IT + 4];
+        out->wave_refills = h[CTL_MAX_IT + 5];
+        out->self_hit_rays = h[CTL_MAX_IT + 6];
+        out->step_lanes = h[CTL_MAX_IT + 7];
     }
     for (size_t i = 0; i < ctx->events_used; ++i) {
         float ms = 0.f;
@@ -1017,7 +1024,7 @@ int rt_stats_reset(rt_context* ctx) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     DeviceGuard g(ctx->device);
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if (ctx->stats_dev) HIP_TRY(ctx, hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 3) * sizeof(unsigned long long)));
+    if (ctx->stats_dev) HIP_TRY(ctx, hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 1 + N_STAT64) * sizeof(unsigned long long)));
     ctx->events_used = 0; ctx->hit_ms = 0; ctx->hit_launches = 0; ctx->paths_total = 0; ctx->rays0_total = 0;
     return 0;
 }

@@ -31,10 +31,13 @@ constexpr int CTL_FETCH = CTL_MAX_IT + 8;     // [segment][it] dynamic-fetch cur
 constexpr int CTL_FETCH_SEGS = RT_FETCH_SEGS;             //   into 8 segments with one cursor each (a single address sustains ~90 atomics/us)
 constexpr int CTL_FETCH_STRIDE = CTL_MAX_IT + 8;   // words between the cursors of two segments: different cache lines
 constexpr int CTL_OVERFLOW = CTL_FETCH + CTL_FETCH_SEGS * CTL_FETCH_STRIDE;
-constexpr int CTL_NODES_LO = CTL_OVERFLOW + 2;   // 64-bit counters: even word index = 8-byte aligned
-constexpr int CTL_PRIMS_LO = CTL_OVERFLOW + 4;
-constexpr int CTL_WORDS = CTL_OVERFLOW + 8;
-static_assert(CTL_NODES_LO % 2 == 0 && CTL_PRIMS_LO % 2 == 0, "64-bit counters must be 8-byte aligned");
+// 64-bit counters of the counters build (RT_FLAG_COUNTERS), even word index = 8-byte aligned:
+//   0 BVH nodes visited (lanes)   1 primitives tested (lanes)   2 node steps (waves)   3 leaf steps (waves)
+//   4 refills (waves)             5 rays that re-hit their own triangle (no traversal)  6 lanes with work summed over the steps
+constexpr int CTL_STAT64 = CTL_OVERFLOW + 2;
+constexpr int N_STAT64 = 8;
+constexpr int CTL_WORDS = CTL_STAT64 + 2 * N_STAT64;
+static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 
 // Ray queue, structure of arrays of 16-byte words so that every wave-level access
 // is one contiguous 1 KiB transaction:
@@ -77,6 +80,7 @@ struct DevScene {
     uint32_t n_prims;         // all primitive records
     uint32_t n_leaf_prims;    // records [0, n_leaf_prims) are referenced by BVH leaves; the rest are big spheres
     uint32_t n_nodes;
+    uint32_t n_tris;          // triangles among the primitives (0: k_shade runs its variant without the f64 triangle arithmetic)
     const float4* planes;     // 2 x float4 per plane: (c.xyz, bits(gid)), (n.xyz, bits(material))
     const int32_t* plane_object;
     uint32_t n_planes;

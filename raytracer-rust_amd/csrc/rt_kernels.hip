@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ prims = sc.prims;
-    uint32_t cnt_nodes = 0, cnt_prims = 0;
+    uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_wnode = 0, cnt_wleaf = 0, cnt_wrefill = 0, cnt_self = 0, cnt_lanes = 0;   // counters build only
     // The queue is cut into CTL_FETCH_SEGS segments, each with its own cursor.  A wave starts in the
     // segment of its block (consecutive blocks go to different XCDs) and moves on to the next one
     // when a segment is used up, so the cursors see an eighth of the atomics each and the ranges can
@@ -394,6 +394,8 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         {
             const uint64_t idle = __ballot(!active);
             if (idle != 0ull) {
+                asm volatile("; RTMARK refill");      // (region markers for tools/isa_histogram.py: comments, no code)
+                if (COUNT) cnt_wrefill++;
                 while (cur >= cur_end && !exhausted) {
                     const uint32_t seg_begin = seg * seg_len, seg_end = min(seg_begin + seg_len, n);
                     uint32_t base = 0;
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     const bool take = !active && cand < cur_end;
                     cur = min(cur + (uint32_t)__popcll(idle), cur_end);
                     if (take) {
+                        asm volatile("; RTMARK refill_take");
                         ray = cand;
                         // A refill is a chain of dependent memory round trips during which the wave's other
                         // lanes wait, so it is kept to one: the ray words a and b.  Planes and big spheres come
@@ -429,6 +432,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             // the ray re-hits the triangle it starts on at t ~ 1e-16 (k_shade's verdict, see tri_hit_ref):
                             // nothing can be closer, no traversal
                             hits[ray] = make_float2(0.f, __uint_as_float(src & SRC_PRIM_MASK));
+                            if (COUNT) cnt_self++;
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
                             best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu;
@@ -483,6 +487,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 }
             }
         }
+        asm volatile("; RTMARK control");
         if (__ballot(active) == 0ull) {
             if (exhausted) break;
             continue;
@@ -507,7 +512,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
             // 12 % slower.)
             const uint32_t nn = (uint32_t)__popcll(__ballot(nodem)), nl = (uint32_t)__popcll(__ballot(leafm));
             const bool do_node = nn * RT_VOTE_WL >= nl * RT_VOTE_WN;
+            if (COUNT) { if (do_node) cnt_wnode++; else cnt_wleaf++; cnt_lanes += (do_node ? nodem : leafm) ? 1u : 0u; }
             if (do_node && nodem) {
+                asm volatile("; RTMARK node");
                 int32_t nxt;
                 const float4* __restrict__ base = nodes + 4 * (size_t)node;
                 const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
@@ -582,15 +589,18 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     nxt = pop(sp);
                 }
                 node = nxt;
+                asm volatile("; RTMARK control");
             }
             if (!do_node && leafm) {
+                asm volatile("; RTMARK leaf");
                 const float4* __restrict__ base = prims + 3 * (size_t)pcur;
                 const float4 L0 = base[0], L1 = base[1], L2 = base[2];
                 if (COUNT) cnt_prims++;
                 const uint32_t pi = pcur;
                 const uint32_t gid = __float_as_uint(L2.y);
                 if (__float_as_uint(L2.z) == PRIM_TRIANGLE) {
-                    if (pi != src) {   // the src triangle was tested at refill
+                    if (pi != src) {   // a ray does not hit the triangle it leaves (k_shade's verdict, SRC_SELF_BIT otherwise)
+                        asm volatile("; RTMARK leaf_tri");
                         // intersections.rs:148-168 (Cramer's rule == Moeller-Trumbore):
                         // a = Ma/M, b = Mb/M, t = -Mt/M; reject a<0 || b<0 || a+b>1 || t<0 (no epsilon)
                         const f3 v0 = mk(L0.x, L0.y, L0.z), e1 = mk(L0.w, L1.x, L1.y), e2 = mk(L1.z, L1.w, L2.x);
@@ -611,10 +621,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     // (o and d are laundered so that their f64 copies are made here: hoisted out of the loop
                     // they occupy 14 registers for the whole kernel, the difference between 6 and 8 waves/SIMD)
                     f3 o_ = o, d_ = d;
-                    asm volatile("" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
+                    asm volatile("; RTMARK leaf_sphere" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
                     const float t = sphere_hit(L0, L1, o_, d_, src == pi);
                     if (t > 0.f) consider(best, t, pi, gid);
                 }
+                asm volatile("; RTMARK leaf_end");
                 pcur++;
                 if (pcur == pend && node < 0) {
                     // the leaf that was waiting moves in, the stack gives the next piece of work
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     pend = pcur + (code & 7u) + 1u;
                     node = pop(sp);
                 }
+                asm volatile("; RTMARK control");
             }
             if (active && node == STACK_SENTINEL && pcur >= pend) {
                 hits[ray] = make_float2(best.t, __uint_as_float(best.code));
@@ -634,15 +646,24 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         }
     }
     if (COUNT) {
-        // wave reduction, one 64-bit add per wave
-        uint64_t cn = cnt_nodes, cp = cnt_prims;
+        // wave reduction of the per-lane counters, one 64-bit add per wave and counter; the per-wave counters are
+        // wave-uniform, lane 0 holds them
+        uint64_t cn = cnt_nodes, cp = cnt_prims, cs = cnt_self, cl = cnt_lanes;
         for (int off = 32; off > 0; off >>= 1) {
             cn += __shfl_down(cn, off);
             cp += __shfl_down(cp, off);
+            cs += __shfl_down(cs, off);
+            cl += __shfl_down(cl, off);
         }
         if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl[CTL_NODES_LO]), (unsigned long long)cn);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl[CTL_PRIMS_LO]), (unsigned long long)cp);
+            unsigned long long* st64 = reinterpret_cast<unsigned long long*>(&ctl[CTL_STAT64]);
+            atomicAdd(st64 + 0, (unsigned long long)cn);
+            atomicAdd(st64 + 1, (unsigned long long)cp);
+            atomicAdd(st64 + 2, (unsigned long long)cnt_wnode);
+            atomicAdd(st64 + 3, (unsigned long long)cnt_wleaf);
+            atomicAdd(st64 + 4, (unsigned long long)cnt_wrefill);
+            atomicAdd(st64 + 5, (unsigned long long)cs);
+            atomicAdd(st64 + 6, (unsigned long long)cl);
         }
     }
 }
@@ -705,7 +726,10 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 #define RT_SHADE_THREADS 1024
 #endif
 #ifndef RT_SHADE_MINWAVES
-#define RT_SHADE_MINWAVES 4   // (the f64 hit-point / self-intersection arithmetic needs ~90 VGPRs)
+#define RT_SHADE_MINWAVES 8   // scenes without triangles: <= 64 VGPRs, two 1024-thread blocks per CU, one computes while the other waits at its barriers
+#endif
+#ifndef RT_SHADE_MINWAVES_TRIS
+#define RT_SHADE_MINWAVES_TRIS 4   // with triangles: the f64 hit-point / self-intersection arithmetic needs ~90 VGPRs (64 with spills: 30 % slower)
 #endif
 #ifndef RT_SHADE_GRID_MUL
 #define RT_SHADE_GRID_MUL 2u
@@ -733,7 +757,8 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
-__global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
+template <bool TRIS>
+__global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
@@ -786,7 +811,7 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
                     const float4 S = rec[0];
                     const uint32_t sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
-                    if (!(sw & SMETA_SPHERE)) {
+                    if (TRIS && !(sw & SMETA_SPHERE)) {
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
                         // t, the hit point and the barycentrics with the reference's own f64 sequence on its own f64
                         // operands (see tri_hit_ref).  The ray enters it as f64: the exact eye for a primary ray, the
@@ -874,7 +899,7 @@ __global__ __launch_bounds__(SHADE_THREADS, RT_SHADE_MINWAVES) void k_shade(DevS
         // see tri_hit_ref.)  The reference's f64 test on the f64 hit point; the verdict travels in the src word.
         auto leaves_src = [&](f3 dir_out, uint32_t& src_out) -> bool {
             src_out = code;
-            if (!on_tri) return false;
+            if (!TRIS || !on_tri) return false;
             const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
             const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
             const d3 nd64 = dither64(dir_out, dh);
@@ -1039,8 +1064,7 @@ __global__ void k_stats(const uint32_t* __restrict__ ctl, unsigned long long* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > 0 && i < CTL_MAX_IT) stats[i] += min(ctl[CTL_QCOUNT + i], capacity);   // iteration 0: host-side count of valid pixels
     if (i == CTL_MAX_IT) stats[i] += ctl[CTL_OVERFLOW];
-    if (i == CTL_MAX_IT + 1) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_NODES_LO]);
-    if (i == CTL_MAX_IT + 2) stats[i] += *reinterpret_cast<const unsigned long long*>(&ctl[CTL_PRIMS_LO]);
+    if (i > CTL_MAX_IT && i <= CTL_MAX_IT + N_STAT64) stats[i] += reinterpret_cast<const unsigned long long*>(&ctl[CTL_STAT64])[i - CTL_MAX_IT - 1];
 }
 
 }  // namespace
@@ -1065,7 +1089,8 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
@@ -1085,7 +1110,7 @@ void launch_calib_gather(const float4* table, uint32_t n_records, uint32_t iters
     hipLaunchKernelGGL(k_calib_gather, dim3(blocks), dim3(256), 0, st, table, n_records, iters, sink);
 }
 void launch_stats(const uint32_t* ctl, unsigned long long* stats, uint32_t capacity, hipStream_t st) {
-    hipLaunchKernelGGL(k_stats, dim3(cdiv(CTL_MAX_IT + 3, 64)), dim3(64), 0, st, ctl, stats, capacity);
+    hipLaunchKernelGGL(k_stats, dim3(cdiv(CTL_MAX_IT + 1 + N_STAT64, 64)), dim3(64), 0, st, ctl, stats, capacity);
 }
 
 }  // namespace rtamd

@@ -44,6 +44,25 @@ def partition(params, rank, world, split="spp"):
     return p
 
 
+def bench_step_params(step, rank, world, spp, grid_n, split):
+    """Partition arithmetic of one bench.py step: (sample_begin, sample_end, tile_index, tile_count) of `rank`.
+
+    Sample split (weak scaling): every rank renders the full frame for `spp` cells of the grid_n x grid_n jitter grid
+    of its own; the cell ranges of the ranks of one step are disjoint and consecutive, and successive steps move on
+    through the grid (wrapping after grid_n^2 cells).  Tile split (strong scaling): every rank renders the same `spp`
+    cells on its own tiles (tile t -> rank t % world)."""
+    cells = grid_n * grid_n
+    if spp <= 0 or cells % spp:
+        raise ValueError("spp per step must divide the %d cells of the grid" % cells)
+    if split == "spp":
+        c0 = ((step * world + rank) * spp) % cells
+        return c0, c0 + spp, 0, 1
+    if split == "tiles":
+        c0 = (step * spp) % cells
+        return c0, c0 + spp, rank, world
+    raise ValueError(split)
+
+
 def reduce_to_root(accum, dst=0):
     """Sum of the ranks' partial accumulators on `dst` (in place on dst).  accum: torch tensor."""
     import torch.distributed as dist

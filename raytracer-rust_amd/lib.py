@@ -47,6 +47,8 @@ class StatsC(C.Structure):
         ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("queue_overflow", C.c_uint64),
         ("hit_launches", C.c_uint32), ("hit_ms", C.c_double),
         ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_prims", C.c_uint32), ("bvh_build_ms", C.c_double),
+        ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_refills", C.c_uint64), ("self_hit_rays", C.c_uint64),
+        ("step_lanes", C.c_uint64),
     ]
 
 

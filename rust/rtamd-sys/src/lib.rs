@@ -93,6 +93,11 @@ pub struct rt_stats {
     pub bvh_depth: u32,
     pub bvh_prims: u32,
     pub bvh_build_ms: f64,
+    pub wave_node_steps: u64,
+    pub wave_leaf_steps: u64,
+    pub wave_refills: u64,
+    pub self_hit_rays: u64,
+    pub step_lanes: u64,
 }
 
 extern "C" {

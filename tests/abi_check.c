@@ -2,8 +2,8 @@
  * Rust `-sys` crate (rust/rtamd-sys/src/lib.rs) assumes -- and pins the size of every struct and the offset and
  * size of every field (LP64).  Built by __graft_entry__.build() with
  *   gcc -std=c11 -Wall -Werror -pedantic -o tests/abi_check tests/abi_check.c
- * so a layout change breaks the build until this table, raytracer-rust_amd/lib.py (ctypes) and
- * rust/rtamd-sys/abi_layout.json (the table rust/rtamd-sys/src/lib.rs is stated to follow) are updated together.
+ * so a layout change breaks the build until this table (tools/gen_abi_check.py), raytracer-rust_amd/lib.py (ctypes)
+ * and rust/rtamd-sys/abi_layout.json (the table rust/rtamd-sys/src/lib.rs is stated to follow) are updated together.
  * Run, it prints the layout as JSON; tests/test_abi.py compares that with the ctypes structs and the table.
  * Reference seam: /root/reference/src/raytracer/raytrace.rs:108-156, /root/reference/src/main.rs:21-26. */
 #include <stddef.h>
@@ -68,7 +68,7 @@ FIELD_IS(rt_render_params, max_shadow_generations, 44, 4);
 FIELD_IS(rt_render_params, flags, 48, 4);
 FIELD_IS(rt_render_params, sample_offset, 56, 16);
 
-SIZE_IS(rt_stats, 2640);
+SIZE_IS(rt_stats, 2680);
 FIELD_IS(rt_stats, rays_total, 0, 8);
 FIELD_IS(rt_stats, rays_per_iteration, 8, 2560);
 FIELD_IS(rt_stats, paths, 2568, 8);
@@ -81,6 +81,11 @@ FIELD_IS(rt_stats, bvh_nodes, 2616, 4);
 FIELD_IS(rt_stats, bvh_depth, 2620, 4);
 FIELD_IS(rt_stats, bvh_prims, 2624, 4);
 FIELD_IS(rt_stats, bvh_build_ms, 2632, 8);
+FIELD_IS(rt_stats, wave_node_steps, 2640, 8);
+FIELD_IS(rt_stats, wave_leaf_steps, 2648, 8);
+FIELD_IS(rt_stats, wave_refills, 2656, 8);
+FIELD_IS(rt_stats, self_hit_rays, 2664, 8);
+FIELD_IS(rt_stats, step_lanes, 2672, 8);
 
 _Static_assert(RT_MAX_ITERATIONS == 320, "RT_MAX_ITERATIONS changed");
 _Static_assert(RT_MAT_LAMBERTIAN == 0 && RT_MAT_METAL == 1 && RT_MAT_DIELECTRIC == 2 && RT_MAT_TEXTURE == 3 && RT_MAT_EMISSIVE == 4, "material tags changed");
@@ -196,6 +201,11 @@ int main(void) {
     P_FIELD(rt_stats, bvh_depth);
     P_FIELD(rt_stats, bvh_prims);
     P_FIELD(rt_stats, bvh_build_ms);
+    P_FIELD(rt_stats, wave_node_steps);
+    P_FIELD(rt_stats, wave_leaf_steps);
+    P_FIELD(rt_stats, wave_refills);
+    P_FIELD(rt_stats, self_hit_rays);
+    P_FIELD(rt_stats, step_lanes);
     P_END();
     printf(", \"entry_points\": %zu}\n", (size_t)N_ENTRY_POINTS);
     return 0;

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes computed by hand from include/rtamd.h (LP64)
     assert C.sizeof(libmod.RenderParamsC) == 72
-    assert C.sizeof(libmod.StatsC) == 8 + 8 * 320 + 8 * 4 + 8 + 8 + 16 + 8
+    assert C.sizeof(libmod.StatsC) == 8 + 8 * 320 + 8 * 4 + 8 + 8 + 16 + 8 + 5 * 8
 
 
 def test_no_gpu_context_fails_loudly():
