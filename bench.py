@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0        # aggregate L2 bandwidth
 VALU_PEAK_TFLOPS = 157.3     # peak FP32 vector
+REHEARSAL = os.environ.get("RTAMD_BENCH_REHEARSAL", "") == "gloo"    # see main()
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 VALU_PIPE_PEAK_GCYC = N_SIMD * CLOCK_GHZ     # VALU pipe cycles available per second, in 1e9
@@ -113,7 +114,12 @@ def run_workload(rt, scenegen, args, workload, rank, world, dev, steps, warmup, 
             # the exchange step of the sample split: sum the partial accumulators on rank 0 over xGMI
             # (tile split: the ranks' tiles are disjoint, the same reduce assembles the frame)
             total.copy_(accum)
-            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
+            if REHEARSAL:
+                host = total.cpu()                      # gloo has no reduce for device tensors
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                total.copy_(host)
+            else:
+                dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
             src = total
         else:
             src = accum
@@ -148,8 +154,9 @@ def run_workload(rt, scenegen, args, workload, rank, world, dev, steps, warmup, 
     barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(st["rays_total"]), float(st["paths"])], dtype=torch.float64, device=dev)
+    cdev = "cpu" if REHEARSAL else dev
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    rays = torch.tensor([float(st["rays_total"]), float(st["paths"])], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -222,7 +229,7 @@ def run_workload(rt, scenegen, args, workload, rank, world, dev, steps, warmup, 
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, depth %d, %d spp/step%s of a jitter:%d grid, %s split%s" %
                                    (name, W, H, args.depth, spp, "/GPU" if split == "spp" else "", grid_n, split,
-                                    " [SMALL: not a measurement]" if args.small else ""),
+                                    " [SMALL: not a measurement]" if args.small else "") + (" [REHEARSAL over gloo on shared GPUs: not a measurement]" if REHEARSAL else ""),
                        "paths_per_step": total_paths / steps, "rays_per_path": total_rays / max(1.0, total_paths),
                        "samples_per_s": total_paths / elapsed, "mesh_share_of_primary_hits": mesh_share,
                        "mesh_winding": "outward (lit torus)", "bvh_nodes": st["bvh_nodes"], "bvh_depth": st["bvh_depth"],
@@ -299,10 +306,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if REHEARSAL:
+        # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: every rank on a GPU it shares, the
+        # collectives over gloo on host copies.  NOT a measurement (the JSON line says so); the driver's runs use RCCL.
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if REHEARSAL:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     split = args.split or ("tiles" if args.workload == "c4" else "spp")
     out, sc = run_workload(rt, scenegen, args, args.workload, rank, world, dev, args.steps, args.warmup, split)

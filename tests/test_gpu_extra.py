@@ -224,3 +224,30 @@ def test_accum_reduce_on_device_tensors(ctx):
     rt.accum_reduce(ctx, a, [ctx], [b])
     torch.cuda.synchronize()
     assert torch.equal(a.cpu(), torch.arange(27, dtype=torch.float32).reshape(3, 3, 3) + 1)
+
+
+@pytest.mark.parametrize("ranks,workload,scaling", [(2, "c5", "weak"), (3, "c4", "strong")])
+def test_bench_multi_rank_control_flow(ranks, workload, scaling, tmp_path):
+    """bench.py's N > 1 branch (process group, per-rank partition, reduce to rank 0, max-over-ranks timing, summed ray
+    counts) executed end to end with several ranks sharing this box's one GPU: RTAMD_BENCH_REHEARSAL=gloo swaps RCCL for
+    gloo on host copies, everything else is the code the driver's multi-GPU runs execute."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RTAMD_BENCH_REHEARSAL="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--small",
+                        "--workload", workload], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1                                     # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == ranks and j["scaling"] == scaling and j["value"] > 0 and "REHEARSAL" in j["config"]["workload"]
+    w, h = (320, 180) if workload == "c5" else (384, 216)
+    per_step = w * h * 64 * (ranks if scaling == "weak" else 1)          # weak: every rank renders the frame; strong: the ranks share it
+    assert j["config"]["paths_per_step"] == per_step
+    assert "cpu_baseline" not in j and "other_workloads" not in j         # N = 1 only
