@@ -277,8 +277,8 @@ def render_north_star(rt, scenegen, out_png=None, n=32, depth=5, seed=2026, devi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="c5", choices=["c3", "c4", "c5"])
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--depth", type=int, default=5)
