@@ -327,10 +327,14 @@ def main():
         if world == 1 and not args.no_other_workloads:
             # the other two BASELINE configurations, driver-timed in the same run (fewer steps: they are context, not the headline)
             others = {}
-            for w in ("c3", "c4"):
+            for w in ("c3", "c4", "c3_depth50"):
                 if w == args.workload:
                     continue
-                o, _ = run_workload(rt, scenegen, args, w, 0, 1, dev, max(2, args.steps // 2), 1, "tiles" if w == "c4" else "spp")
+                wl, depth0 = w, args.depth
+                if w == "c3_depth50":                     # C3 at the reference's default depth 5 and at RTIOW's 50
+                    wl, args.depth = "c3", 50
+                o, _ = run_workload(rt, scenegen, args, wl, 0, 1, dev, max(2, args.steps // 2), 1, "tiles" if wl == "c4" else "spp")
+                args.depth = depth0
                 r = o["roofline"]
                 others[w] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
                              "steps": o["steps"], "samples_per_s": o["config"]["samples_per_s"], "rays_per_path": o["config"]["rays_per_path"],

@@ -199,6 +199,12 @@ int rt_context_create(int device_id, rt_context** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->stats_dev, (CTL_MAX_IT + 1 + N_STAT64) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->stats_dev, 0, (CTL_MAX_IT + 1 + N_STAT64) * sizeof(unsigned long long));
     if (e != hipSuccess) { rt_context_destroy(ctx); return fail(nullptr, "hipMalloc: %s", hipGetErrorString(e)); }
+    // The kernels' code object is loaded (and whatever the runtime allocates for it, allocated) at the first launch on a
+    // device: do that here, so that no later entry point -- rt_render_accumulate_noalloc under graph capture least of all --
+    // is the first.  (The control block is all zero: the statistics kernel adds nothing.)
+    e = hipMemset(ctx->ctl, 0, CTL_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) { launch_stats(ctx->ctl, ctx->stats_dev, 0u, nullptr); e = hipDeviceSynchronize(); }
+    if (e != hipSuccess) { rt_context_destroy(ctx); return fail(nullptr, "first kernel launch failed: %s", hipGetErrorString(e)); }
     {   // device address of the no-alloc scratch array, once per device, with that device current
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
         if (device_id < (int)(sizeof(g_scratch_ptr) / sizeof(g_scratch_ptr[0])) && !g_scratch_ptr[device_id]) {
@@ -831,6 +837,7 @@ int rt_accum_reduce(rt_context* dst, float* dst_accum_dev, rt_context* const* sr
     hipStream_t st = (hipStream_t)stream;
     for (uint32_t k = 0; k < n_src; ++k) {
         if (!src[k] || !src_accum_dev[k]) return fail(dst, "source %u is NULL", k);
+        if (src_accum_dev[k] == dst_accum_dev) return fail(dst, "source %u is the destination itself", k);
         if (!src[k]->have_scene || src[k]->sc.width != dst->sc.width || src[k]->sc.height != dst->sc.height)
             return fail(dst, "source %u renders a different frame size", k);
         const float* from = src_accum_dev[k];

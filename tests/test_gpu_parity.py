@@ -246,6 +246,25 @@ def test_c3_image_parity_small(ctx):
     assert p >= 40.0
 
 
+def test_c3_image_parity_depth_50(ctx):
+    """SURVEY 8d reports C3 at the reference's default depth 5 and at RTIOW's 50: long glass / metal paths."""
+    sc = scenegen.scene_c3(width=128, height=72)
+    ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
+    osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc))
+    n = 32
+    ctx.stats_reset()
+    acc, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=50, seed=5))
+    st = ctx.stats()
+    assert len(st["rays_per_iteration"]) > 30                     # paths of more than 30 segments exist
+    ref = osc.render(mode="jitter", N=n, depth=50, seed=23)
+    p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
+    bias = abs(np.mean(acc) - np.mean(ref["sum"])) / (n * n)
+    print("C3 128x72 depth 50: PSNR %.2f dB at %d spp, |bias| %.2e, %.2f rays per path (oracle %.2f)"
+          % (p, n * n, bias, st["rays_total"] / st["paths"], ref["rays"] / (128 * 72 * n * n)))
+    assert p >= 40.0 and bias <= 1e-3
+    assert abs(st["rays_total"] / st["paths"] - ref["rays"] / (128 * 72 * n * n)) < 0.01
+
+
 def test_c5_image_parity_small(ctx):
     """Lambertian mesh + spheres: exercises the triangle self-hit quirk on a curved mesh."""
     sc = scenegen.scene_c5(width=128, height=72, nu=60, nv=30)
