@@ -351,6 +351,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         if (sp_ >= LDS_STACK) v = spill[(size_t)(sp_ - LDS_STACK) * 64u];
         return (int32_t)v;
     };
+    // A launch is sized for the most rays the iteration can have (the host does not wait for the count).  Blocks the
+    // actual queue has no ray for leave at once: every wave that stays probes all fetch segments before it gives up, and
+    // with thousands of idle waves those atomics -- not the few rays -- set the time of a small launch (the late
+    // iterations of deep paths, the shadow-ray generations).
+    if ((uint64_t)blockIdx.x * blockDim.x >= (uint64_t)min(ctl[CTL_QCOUNT + it], capacity) + 64u * CTL_FETCH_SEGS) return;
     // planes and big spheres (what every ray tests outside the BVH) staged in LDS
     constexpr uint32_t FIXED_PLANES = 4, FIXED_SPHERES = 4;
     __shared__ v4f fixed[2 * FIXED_PLANES + 3 * FIXED_SPHERES];
