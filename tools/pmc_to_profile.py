@@ -27,6 +27,10 @@ for kern in ("k_closest_hit", "k_shade"):
     v = summ[kern]
     n = v["_dispatches"]
     rays = r["rays_per_launch"] * r["launches"]          # rays of the timed step = what these dispatches traced
+    if kern == "k_shade":
+        # k_shade also runs in bench.py's counters step (same rays once more; only k_closest_hit has a counters variant
+        # that the summary keeps apart): its dispatches cover the rays as many times as they outnumber the timed launches
+        rays *= n / float(r["launches"])
     g = lambda k: v.get(k, 0.0)
     f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
     cycles = 2.0 * g("SQ_INSTS_VALU") + 2.0 * (f64 + g("SQ_INSTS_VALU_TRANS_F32")) + 6.0 * g("SQ_INSTS_VALU_TRANS_F64")
