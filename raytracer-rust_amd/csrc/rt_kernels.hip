@@ -736,6 +736,9 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 #ifndef RT_SHADE_MINWAVES_TRIS
 #define RT_SHADE_MINWAVES_TRIS 4   // with triangles: the f64 hit-point / self-intersection arithmetic needs ~90 VGPRs (64 with spills: 30 % slower)
 #endif
+#ifndef RT_SHADE_PREFETCH
+#define RT_SHADE_PREFETCH 1
+#endif
 #ifndef RT_SHADE_GRID_MUL
 #define RT_SHADE_GRID_MUL 2u
 #endif
@@ -770,7 +773,18 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const uint32_t n_pad = (n + (SHADE_THREADS - 1)) & ~(uint32_t)(SHADE_THREADS - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {   // block-uniform trip count
+    // The ray and hit words of a round are loaded one round ahead (RT_SHADE_PREFETCH), right before the round's slot claim:
+    // a round is a chain of dependent waits (queue words, shading record, the claim's atomic between two barriers) that all
+    // 16 waves of the block walk in step, and this takes the first link off it.
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA, nC = nA;
+    float2 nH = make_float2(0.f, 0.f);
+    auto load_round = [&](uint32_t j) {
+        nA = qi.a[j]; nH = hits[j];
+        if (it != 0) { nB = qi.b[j]; nC = qi.c[j]; }
+    };
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (RT_SHADE_PREFETCH && i < n) load_round(i);
+    for (; i < n_pad; i += stride) {   // block-uniform trip count
         bool emit = false;       // continue with a scattered ray
         bool fire = false;       // spawn shadow rays
         bool on_tri = false;     // the hit is on a triangle: p64 is its f64 hit point
@@ -778,8 +792,9 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         d3 p64 = mkd(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
         if (i < n) {
-            const float4 A = qi.a[i];
-            const float2 H = hits[i];
+            if (!RT_SHADE_PREFETCH) load_round(i);
+            const float4 A = nA;
+            const float2 H = nH;
             f3 o, d;
             uint32_t src = SRC_NONE;
             if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
@@ -788,7 +803,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 thr = mk(1.f, 1.f, 1.f);
                 rng = __float_as_uint(A.w);
             } else {
-                const float4 B = qi.b[i], C = qi.c[i];
+                const float4 B = nB, C = nC;
                 o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
                 src = __float_as_uint(B.z);
                 pid = __float_as_uint(B.w);
@@ -913,13 +928,20 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             src_out = code | SRC_SELF_BIT;
             return true;
         };
+        uint32_t src_next = code;
+        bool self_next = false;
+        if (!last && emit) self_next = leaves_src(ndir, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
+        if (RT_SHADE_PREFETCH) {
+            const uint64_t j = (uint64_t)i + stride;
+            if (j < n) load_round((uint32_t)j);
+        }
         if (!last) {
             // (ordering the block's slots by the octant of the new direction was measured: no gain)
             const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
             if (emit) {
                 if (slot < capacity) {
-                    uint32_t src_out;
-                    const bool self = leaves_src(ndir, src_out);
+                    const uint32_t src_out = src_next;
+                    const bool self = self_next;
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
                     qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
