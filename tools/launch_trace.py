@@ -19,8 +19,10 @@ step = [s for s in steps if any("k_closest_hit<false>" in r["Kernel_Name"] for r
 step = step[:max(i for i, r in enumerate(step) if "k_accumulate" in r["Kernel_Name"] or "k_shade" in r["Kernel_Name"]) + 1]
 hit = [r for r in step if "k_closest_hit" in r["Kernel_Name"]]
 shade = [r for r in step if "k_shade" in r["Kernel_Name"]]
+passes = max(1, round(line["roofline"]["launches"] / (line["steps"] * max(1, len(hit)))))   # a step of C4 is several passes: the trace shows the last one
+per_it = [x / passes for x in per_it]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-print("raygen %.0f us" % dur(step[0]))
+print("last pass of the last timed step (%d pass%s per step); raygen %.0f us" % (passes, "" if passes == 1 else "es", dur(step[0])))
 print(" it        rays   hit us  ns/ray  shade us  ns/ray  shade GB/s (algorithmic)")
 for it, (h, s) in enumerate(zip(hit, shade)):
     n = per_it[it] if it < len(per_it) else 0
