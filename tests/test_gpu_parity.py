@@ -290,6 +290,38 @@ def test_golden_plateaus_of_the_reference_renders(ctx):
         assert (gm & mm).sum() >= minimum * gm.sum(), (name, (gm & mm).sum(), gm.sum())
 
 
+def test_converged_renders_match_the_reference_pngs(ctx):
+    """The reference's own renders (scenes/*/*.png, settings unknown) against converged device renders: the only outputs of
+    the real reference this repository can hold, and so the pin of everything its unit tests leave open -- Camera::new /
+    spawn_ray, Ray::trace with the light-sampling branch, the materials, texture lookup, OBJ import, compute_image's
+    mean / sqrt / clamp / quantise.  Measured (tools/golden_psnr.py, depth 12):
+
+        spp (jitter:n)      spheres.png            cube.png             (4x4 = both images box-filtered 4x4 first)
+        1024  (32)      46.9 dB, 4x4 59.0 dB   52.4 dB, 4x4 61.4 dB
+        4096  (64)      50.5 dB, 4x4 62.5 dB   54.7 dB, 4x4 62.8 dB
+        40000 (200)     52.5 dB, 4x4 64.2 dB   55.8 dB, 4x4 62.3 dB    mean difference +0.002 / +0.003 of 255 levels
+
+    Two independently quantised 8-bit images of the same radiance differ by 55.9 dB, so at 40,000 spp the device's frame and
+    the reference's are apart by the rounding to 8 bits and the goldens' own residual noise.  The same figures hold for every
+    depth >= 8 (spheres) / >= 3 (cube); at the CLI's default depth 5 spheres.png is 5 dB worse after filtering (53.6 dB at
+    1024 spp, mean -0.08): it was rendered with more than 5 bounces.  The oracle gives the same numbers (46.91 / 52.41 dB at
+    1024 spp; tests/test_oracle_kat.py runs it at 256 spp)."""
+    from PIL import Image
+    box = lambda a: a.reshape(125, 4, 125, 4, 3).mean(axis=(1, 3))
+    psnr = lambda a, b: 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+    for name, raw_db, filtered_db in (("spheres", 49.5, 60.5), ("cube", 53.5, 61.0)):
+        load_pair(name, ctx)
+        gold = np.asarray(Image.open(os.path.join(GOLDEN, "scenes", name, name + ".png")).convert("RGB")).astype(float)
+        _, rgb = ctx.render_image(rt.RenderParams("jitter:64", depth=12, seed=11))
+        img = rgb.astype(float)
+        assert psnr(img, gold) >= raw_db, (name, psnr(img, gold))
+        assert psnr(box(img), box(gold)) >= filtered_db, (name, psnr(box(img), box(gold)))
+        assert abs((img - gold).mean()) <= 0.02, (name, (img - gold).mean())
+        # the gate sees a missing bounce: short of convergence in depth the same render fails it by far
+        _, rgb = ctx.render_image(rt.RenderParams("jitter:32", depth=3 if name == "spheres" else 1, seed=11))
+        assert psnr(box(rgb.astype(float)), box(gold)) < 30.0
+
+
 # ------------------------------------------------------------------ properties
 def test_tile_split_union_is_bit_identical(ctx):
     load_pair("spheres", ctx)

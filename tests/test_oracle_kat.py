@@ -333,17 +333,25 @@ def test_oracle_reproduces_deterministic_pixels_of_cube_png(golden_dir):
     assert both > 0.5 * g114.sum()
 
 
-def test_oracle_image_close_to_goldens(golden_dir):
-    """Loose visual parity with the two committed renders (settings unknown =>
-    parity unpinned beyond this)."""
-    for name, thresh in (("spheres", 25.0), ("cube", 20.0)):
+def test_oracle_image_matches_the_reference_pngs(golden_dir):
+    """The pin of the oracle's whole path (camera, Ray::trace with the light branch, materials, texture, OBJ import,
+    compute_image) on outputs of the REAL reference: its two committed renders, settings unknown.  Measured at depth 12:
+    256 spp (this test, ~8 s): spheres 41.8 dB, 53.7 dB after a 4x4 box filter of both images (which removes most of the
+    sampling noise of either side), mean difference -0.03 of 255 levels; cube 48.5 / 59.9 dB, -0.01.  At 1024 spp: 46.9 /
+    58.9 dB and 52.4 / 61.3 dB, mean -0.004 -- the device path gives the same figures and goes on to 52.5 / 55.8 dB at
+    40,000 spp (tests/test_gpu_parity.py::test_converged_renders_match_the_reference_pngs), where 55.9 dB is what two
+    independent 8-bit quantisations of one image differ by.  spheres.png needs depth >= 8 (at the CLI default 5 the mean
+    is off by -0.08 levels): its settings were not the defaults."""
+    box = lambda a: a.reshape(125, 4, 125, 4, 3).mean(axis=(1, 3))
+    psnr = lambda a, b: 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+    for name, raw_db, filtered_db in (("spheres", 40.5, 52.0), ("cube", 47.0, 58.0)):
         gold = _golden_facts(os.path.join(golden_dir, "scenes/%s/%s.png" % (name, name))).astype(np.float64)
         sc = O.OracleScene.from_yaml(os.path.join(golden_dir, "scenes/%s/%s.yaml" % (name, name)), base_dir=golden_dir)
-        out = sc.render(mode="jitter", N=4, depth=5, seed=3)["rgb8"].astype(np.float64)
-        mse = np.mean((gold - out) ** 2)
-        psnr = 10 * np.log10(255.0 ** 2 / mse)
-        print(name, "PSNR vs golden", psnr)
-        assert psnr > thresh
+        out = sc.render(mode="jitter", N=16, depth=12, seed=3)["rgb8"].astype(np.float64)
+        print(name, "PSNR vs the reference's PNG", psnr(out, gold), "filtered", psnr(box(out), box(gold)), "mean", (out - gold).mean())
+        assert psnr(out, gold) >= raw_db
+        assert psnr(box(out), box(gold)) >= filtered_db
+        assert abs((out - gold).mean()) <= 0.08
 
 
 # ---------------------------------------------------------------------------
