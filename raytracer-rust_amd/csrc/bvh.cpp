@@ -150,7 +150,7 @@ void encode_node(GpuNode& g, const Box& node_box, const Box* child_boxes, const 
         double ext = (double)node_box.mx[k] - (double)g.p[k];
         if (!(ext > 0.0)) ext = 0.0;
         // smallest power of two s with 255 * s >= ext
-        int e = (ext > 0.0) ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+        int e = (ext > 0.0 && std::isfinite(ext)) ? (int)std::ceil(std::log2(ext / 255.0)) : (ext > 0.0 ? 127 : -126);
         while (e < 127 && std::ldexp(255.0, e) < ext) e++;
         e = std::min(127, std::max(-126, e));
         e8[k] = (uint32_t)(e + 127);
@@ -190,6 +190,13 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
     out.nodes.clear(); out.order.resize(n); out.max_depth = 0;
     for (uint32_t i = 0; i < n; ++i) out.order[i] = i;
     if (n == 0) { out.build_ms = 0; return; }
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(boxes[i].mn[k]) || !std::isfinite(boxes[i].mx[k]) || boxes[i].mn[k] > boxes[i].mx[k]) {
+                char msg[96];
+                snprintf(msg, sizeof msg, "primitive box %u is not finite or is inverted", i);
+                throw std::invalid_argument(msg);
+            }
 
     // The binary tree is split down to single primitives; the collapse below decides which pairs stay one
     // leaf of two (MAX_LEAF_PRIMS) and which become two leaves in free slots of their parent.
@@ -297,7 +304,7 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
             float as_node = INFINITY;
             for (int i = 1; i <= 3; ++i) {
                 const float c = cl[i - 1] + cr[4 - i - 1];
-                if (c < as_node) { as_node = c; part_node[xi] = (uint8_t)i; }
+                if (i == 1 || c < as_node) { as_node = c; part_node[xi] = (uint8_t)i; }   // (i == 1 first: costs that overflowed to inf / NaN must still yield a valid split)
             }
             as_node += area * c_node;
             if (leaf_dp && t.count <= MAX_LEAF_PRIMS && area * (float)t.count * c_prim <= as_node) {

@@ -275,6 +275,24 @@ static int validate_desc(const rt_scene_desc* d, std::string& err) {
         if (d->mat_type[i] == RT_MAT_TEXTURE && (!d->mat_texture || d->mat_texture[i] < 0 || (uint32_t)d->mat_texture[i] >= d->n_textures))
             return bad("material %llu: texture index out of range", i);
     }
+    // Every coordinate must be finite as an f32 (the device's type): the reference would carry NaN / inf through to the
+    // pixels, here they would reach the BVH builder and the traversal's rounding bounds.
+    auto finite_all = [](const double* v, uint64_t n) -> int64_t {
+        for (uint64_t i = 0; i < n; ++i) if (!std::isfinite((float)v[i])) return (int64_t)i;
+        return -1;
+    };
+    int64_t at;
+    if ((at = finite_all(d->sphere_center, 3ull * d->n_spheres)) >= 0) return bad("sphere %llu: centre is not finite", (unsigned long long)at / 3);
+    if ((at = finite_all(d->sphere_radius, d->n_spheres)) >= 0) return bad("sphere %llu: radius is not finite", (unsigned long long)at);
+    if ((at = finite_all(d->plane_center, 3ull * d->n_planes)) >= 0) return bad("plane %llu: centre is not finite", (unsigned long long)at / 3);
+    if ((at = finite_all(d->plane_normal, 3ull * d->n_planes)) >= 0) return bad("plane %llu: normal is not finite", (unsigned long long)at / 3);
+    if ((at = finite_all(d->tri_vertices, 9ull * d->n_triangles)) >= 0) return bad("triangle %llu: a vertex is not finite", (unsigned long long)at / 9);
+    if ((at = finite_all(d->light_point, 3ull * d->n_lights)) >= 0) return bad("light %llu: sample point is not finite", (unsigned long long)at / 3);
+    if (finite_all(d->cam_eye, 3) >= 0 || finite_all(d->cam_lower_left, 3) >= 0 || finite_all(d->cam_horizontal, 3) >= 0 || finite_all(d->cam_vertical, 3) >= 0) {
+        err = "camera vectors are not finite (look_at == eye, up parallel to the view direction, fovy out of range?)";
+        return 1;
+    }
+    if (finite_all(d->background, 3) >= 0) { err = "background is not finite"; return 1; }
     return 0;
 }
 

@@ -750,6 +750,24 @@ def test_invalid_arguments_are_errors(ctx):
         ctx.render_image(rt.RenderParams("jitter:2", tile_index=2, tile_count=2))
 
 
+def test_non_finite_geometry_is_an_upload_error(ctx):
+    """NaN / inf / beyond-f32 coordinates: the reference would carry them into the pixels; here they are refused before they
+    reach the BVH builder (found by tests/host_fuzz.cpp: an infinite box made the node encoder spin)."""
+    em = dict(type="Emissive", color=[1, 1, 1])
+    tri = lambda v: dict(type="Mesh", verts=np.array([[-1.0, -1, 0], [1, -1, 0], [0, v, 0.5]]), tris=np.array([[0, 1, 2]]), materials=[em])
+    for objs in ([dict(type="Sphere", center=[0, float("nan"), 0], radius=1.0, material=em)],
+                 [dict(type="Sphere", center=[0, 0, 0], radius=float("inf"), material=em)],
+                 [dict(type="Sphere", center=[0, 0, 0], radius=1.0, material=em), dict(type="Plane", center=[0, 1e39, 0], normal=[0, 1, 0], material=em)],
+                 [tri(float("-inf"))], [tri(1e300)]):
+        with pytest.raises(rt.RtError, match="not finite"):
+            ctx.upload(rt.Scene.from_objects(37, 21, [0.25, 0.5, 1.0], CAM, objs))
+    with pytest.raises(rt.RtError, match="not finite"):
+        ctx.upload(rt.Scene.from_objects(37, 21, [0.25, float("nan"), 1.0], CAM, []))
+    # the context is still usable
+    small_scene(ctx, [tri(1.5)])
+    assert ctx.render_image(rt.RenderParams("jitter:2", depth=2))[0].any()
+
+
 def test_compute_image_drop_in(ctx, tmp_path):
     """raytracer::compute_image with the reference's four arguments writes the PNG."""
     from PIL import Image
