@@ -251,3 +251,17 @@ def test_bench_multi_rank_control_flow(ranks, workload, scaling, tmp_path):
     per_step = w * h * 64 * (ranks if scaling == "weak" else 1)          # weak: every rank renders the frame; strong: the ranks share it
     assert j["config"]["paths_per_step"] == per_step
     assert "cpu_baseline" not in j and "other_workloads" not in j         # N = 1 only
+
+
+def test_c_abi_host_code_under_asan():
+    """tests/abi_asan_driver.cpp: every entry point of include/rtamd.h from a plain C++ host, the library's host code
+    instrumented with AddressSanitizer + UBSan (built by __graft_entry__.build() / `make -C raytracer-rust_amd/csrc asan`).
+    The driver cross-checks host call == device-pointer call == no-alloc call == two contexts, re-uploads scenes of different
+    sizes and walks the error paths."""
+    exe = os.path.join(ROOT, "tests", "_build", "abi_asan")
+    assert os.path.exists(exe), "tests/_build/abi_asan is missing: run __graft_entry__.build()"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")   # (leaks: the HIP runtime keeps its own at exit)
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "all checks passed" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
