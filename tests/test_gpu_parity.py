@@ -643,6 +643,46 @@ def test_random_soups_match_the_oracle(ctx, seed):
         assert np.array_equal(got[k], got2[k]), k
 
 
+def test_more_planes_and_big_spheres_than_the_kernel_stages_in_lds(ctx):
+    """k_closest_hit keeps the first 4 planes and the first 4 spheres that are too big for the BVH in LDS and reads the rest
+    from global memory; at most 8 spheres stay out of the BVH, further big ones go in.  Seven planes (a room and a slanted
+    mirror), ten spheres of radius 30...200 around a handful of small ones: primary hits against the oracle, and the mirror
+    paths (deterministic) as an image, so that the rays of later iterations cross the same code."""
+    em = lambda r, g, b: dict(type="Emissive", color=[r, g, b])
+    mirror = dict(type="Metal", albedo=[0.9, 0.9, 0.9], fuzziness=0.0)
+    objs = [dict(type="Plane", center=[0, -2.0, 0], normal=[0, 1, 0], material=em(0.2, 0.3, 0.4)),
+            dict(type="Plane", center=[0, 6.0, 0], normal=[0, -1, 0], material=em(0.9, 0.9, 0.9)),
+            dict(type="Plane", center=[-7.0, 0, 0], normal=[1, 0, 0], material=em(0.8, 0.2, 0.2)),
+            dict(type="Plane", center=[7.0, 0, 0], normal=[-1, 0, 0], material=em(0.2, 0.8, 0.2)),
+            dict(type="Plane", center=[0, 0, -12.0], normal=[0, 0, 1], material=em(0.3, 0.3, 0.9)),
+            dict(type="Plane", center=[0, 0, 9.0], normal=[0, 0, -1], material=em(0.5, 0.5, 0.1)),
+            dict(type="Plane", center=[0, -1.0, -8.0], normal=[0.3, 1.0, 0.5], material=mirror)]
+    rng = np.random.default_rng(5)
+    eye = np.array(CAM["eye"])
+    for k in range(10):    # big spheres beyond a point of the room, as seen from the eye: a cap of each is visible
+        r = float(rng.uniform(30.0, 200.0))
+        p = np.array([rng.uniform(-4, 4), rng.uniform(-1.5, 3.0), rng.uniform(-9.0, -3.0)])
+        direction = p - eye + rng.normal(size=3) * 2.0
+        direction /= np.linalg.norm(direction)
+        objs.append(dict(type="Sphere", center=list(p + direction * r), radius=r, material=mirror if k % 3 == 0 else em(0.1 * k, 0.5, 1.0 - 0.1 * k)))
+    for k in range(12):
+        objs.append(dict(type="Sphere", center=list(rng.uniform(-2.5, 2.5, size=3) * np.array([1, 0.6, 1])), radius=float(rng.uniform(0.1, 0.6)),
+                         material=mirror if k % 2 else em(0.7, (0.1 * k) % 1.0, 0.3)))
+    osc = small_scene(ctx, objs, 160, 120)
+    got, want = hits_pair(ctx, osc, 0.5, 0.5, own_camera_id_slack=6)
+    seen = set(np.unique(want["object_id"]).tolist())
+    assert {6, 13, 15, 16} <= seen and len(seen) >= 14       # the 7th plane, big spheres beyond the 4th (LDS) and beyond the 8th (in the BVH)
+    check_hits(got, want)
+    # every path is deterministic (mirrors and emitters only; lights are sampled on the last bounce only, depth is ample)
+    _, rgb = ctx.render_image(rt.RenderParams("grid:2", depth=40, seed=1))
+    want_rgb = osc.render(mode="uniform", N=2, depth=40, seed=1)["rgb8"]
+    diff = np.abs(rgb.astype(int) - want_rgb.astype(int)).max(axis=2)
+    assert len(np.unique(want_rgb.reshape(-1, 3), axis=0)) > 20
+    # +-1 level is f32 against f64 rounding; a reflection off a small sphere amplifies the f32 rounding of a direction, so a few
+    # pixels on the silhouettes seen in a mirror land on the neighbouring emitter
+    assert (diff > 1).mean() < 0.01, (diff > 1).mean()
+
+
 def test_mirror_paths_are_deterministic_and_match_the_oracle(ctx):
     """Perfect mirrors (Metal, fuzziness 0: spheres and a plane, whose intersection tests have an
     epsilon and so never re-hit themselves) in front of emissive meshes and spheres: every path is
