@@ -683,6 +683,48 @@ def test_more_planes_and_big_spheres_than_the_kernel_stages_in_lds(ctx):
     assert (diff > 1).mean() < 0.01, (diff > 1).mean()
 
 
+def test_maximum_depth_and_sample_grid(ctx):
+    """The ends of the parameter ranges: depth 255 (u8::MAX, main.rs:16) with the default 16 shadow generations on top,
+    inside a closed mirror box so that paths really live that long; the largest sample grid (4096 x 4096 cells) over a
+    sub-range of its samples; sample ranges at the very end of the grid."""
+    mirror = dict(type="Metal", albedo=[1.0, 1.0, 1.0], fuzziness=0.0)
+    box = [dict(type="Plane", center=c, normal=n, material=mirror) for c, n in (([0, -3, 0], [0, 1, 0]), ([0, 3, 0], [0, -1, 0]), ([-3, 0, 0], [1, 0, 0]),
+                                                                               ([3, 0, 0], [-1, 0, 0]), ([0, 0, -3], [0, 0, 1]), ([0, 0, 8], [0, 0, -1]))]
+    glow = dict(type="Sphere", center=[0.5, -0.4, 0.3], radius=0.25, material=dict(type="Emissive", color=[1.0, 0.5, 0.25]))
+    osc = small_scene(ctx, box + [glow], 48, 32)
+    ctx.stats_reset()
+    acc, rgb = ctx.render_image(rt.RenderParams("grid:2", depth=255, seed=3))
+    st = ctx.stats()
+    assert st["rays_per_iteration"][254] > 0 and st["queue_overflow"] == 0          # some paths are still bouncing at the last allowed bounce
+    assert all(a >= b for a, b in zip(st["rays_per_iteration"][:255], st["rays_per_iteration"][1:255]))
+    # Albedo 1, fuzziness 0: throughput stays exactly 1 over 255 reflections, so every sample is the emitter's colour, the
+    # background's (a ray can slip through a corner: both sides reject hits closer than 1e-5) or black -- every pixel sum
+    # must be a * E + b * BG with a + b <= 4.  Which of the three a long path ends in is chaotic: the f64 oracle and its
+    # own f32 instantiation differ by 25 % in the lit fraction at this depth (and the f64 oracle by 15 % between two
+    # resolutions: a regular grid in a symmetric mirror box is not a random sample), so only short paths are compared.
+    E, BG = np.array([1.0, 0.5, 0.25]), np.array([0.25, 0.5, 1.0])
+    combos = np.array([a * E + b * BG for a in range(5) for b in range(5 - a)])
+    err = np.abs(acc[:, :, None, :] - combos[None, None]).max(axis=3).min(axis=2)
+    assert err.max() < 1e-4, err.max()
+    want = osc.render(mode="uniform", N=2, depth=255, seed=3)["rgb8"]
+    direct = osc.primary_hits(0.25, 0.25)["object_id"] == 6
+    assert direct.sum() > 5 and np.abs(rgb[direct].astype(int) - want[direct].astype(int)).max() <= 1
+    # After 20 bounces 97 % of the paths are still under way and the lit fraction agrees (f64 oracle 0.6146, its f32 form
+    # 0.6328 per pixel sum; pixel-by-pixel comparisons of mirror paths are test_mirror_paths_are_deterministic_and_match_the_oracle's job:
+    # here the emitter is a light, which every live path samples at random on its last bounce)
+    acc20, _ = ctx.render_image(rt.RenderParams("grid:2", depth=20, seed=3))
+    want20 = osc.render(mode="uniform", N=2, depth=20, seed=3)["sum"]
+    assert abs(acc20[..., 0].mean() / want20[..., 0].mean() - 1.0) < 0.1
+    # the largest grid: 16.7 M cells per pixel, of which the call renders 32 -- first, middle and last ones
+    small_scene(ctx, [glow], 16, 8)
+    n = 4096
+    for s0 in (0, n * n // 2, n * n - 32):
+        a, _ = ctx.render_image(rt.RenderParams("jitter:%d" % n, depth=3, seed=5, sample_begin=s0, sample_end=s0 + 32))
+        assert np.isfinite(a).all() and a.max() <= 32 * 1.0 + 1e-3 and a.min() >= 0.0
+    with pytest.raises(rt.RtError):
+        ctx.render_image(rt.RenderParams("jitter:%d" % (n + 1), depth=3, sample_begin=0, sample_end=4))
+
+
 def test_mirror_paths_are_deterministic_and_match_the_oracle(ctx):
     """Perfect mirrors (Metal, fuzziness 0: spheres and a plane, whose intersection tests have an
     epsilon and so never re-hit themselves) in front of emissive meshes and spheres: every path is
