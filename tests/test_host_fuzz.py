@@ -27,3 +27,15 @@ def test_loaders_and_bvh_builder_survive_mutated_fixtures(tmp_path):
         r = subprocess.run([str(exe), GOLDEN, str(tmp_path / "work"), "120", str(seed)], env=env, capture_output=True, text=True, timeout=400)
         assert r.returncode == 0, r.stderr[-4000:]
         assert "scenes loaded" in r.stdout and " 0 scenes loaded" not in r.stdout, r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_threaded_bvh_builder_under_thread_sanitizer(tmp_path):
+    gxx = shutil.which("g++")
+    exe = tmp_path / "bvh_tsan"
+    csrc = os.path.join(ROOT, "raytracer-rust_amd", "csrc")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", str(exe), os.path.join(ROOT, "tests", "bvh_tsan.cpp"),
+                    os.path.join(csrc, "rt_host.cpp"), os.path.join(csrc, "bvh.cpp"), "-lz", "-lpthread"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-4000:])
+    assert r.stdout.count("rc 0") == 2
