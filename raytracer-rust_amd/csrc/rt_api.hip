@@ -243,6 +243,7 @@ struct FlatScene {
     std::vector<int4> meta, textures;
     std::vector<float> uvs;
     std::vector<int32_t> plane_obj;
+    std::vector<double> planes64;    // centre, normal of every plane as given (f64)
     std::vector<uchar4> texels;
     uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0, n_tris = 0;
     float bg[3], eye[3];
@@ -440,6 +441,8 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
         planes[2 * i] = make_float4((float)d->plane_center[3 * i], (float)d->plane_center[3 * i + 1], (float)d->plane_center[3 * i + 2], gf);
         planes[2 * i + 1] = make_float4((float)d->plane_normal[3 * i], (float)d->plane_normal[3 * i + 1], (float)d->plane_normal[3 * i + 2], mf);
         plane_obj[i] = d->plane_object[i];
+        for (int k = 0; k < 3; ++k) f.planes64.push_back(d->plane_center[3 * i + k]);
+        for (int k = 0; k < 3; ++k) f.planes64.push_back(d->plane_normal[3 * i + k]);
     }
     std::vector<float4>& mats = f.mats;
     mats.assign((size_t)d->n_materials * 2, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -492,7 +495,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     free_scene(ctx);
     DevScene sc{};
     if (upload(ctx, f.nodes, &sc.nodes) || upload(ctx, f.prims, &sc.prims) || upload(ctx, f.meta, &sc.meta) || upload(ctx, f.smeta, &sc.smeta) ||
-        upload(ctx, f.uvs, &sc.uvs) || upload(ctx, f.planes, &sc.planes) || upload(ctx, f.plane_obj, &sc.plane_object) ||
+        upload(ctx, f.uvs, &sc.uvs) || upload(ctx, f.planes, &sc.planes) || upload(ctx, f.plane_obj, &sc.plane_object) || upload(ctx, f.planes64, &sc.planes64) ||
         upload(ctx, f.mats, &sc.materials) || upload(ctx, f.textures, &sc.textures) || upload(ctx, f.texels, &sc.texels) ||
         upload(ctx, f.lights, &sc.lights)) {
         free_scene(ctx);

@@ -12,6 +12,8 @@ constexpr uint32_t SRC_NONE = 0xFFFFFFFEu;    // ray does not start on a primiti
 constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: not a ray
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t SRC_SELF_BIT = 0x40000000u;  // src = SRC_SELF_BIT | triangle: the ray re-hits the triangle it starts on at t ~ 0 (decided by k_shade, see there)
+constexpr uint32_t SRC_E_BIT = 0x20000000u;     // src | SRC_E_BIT (src below SRC_SPECIAL): queue word e holds the ray's f64 origin (it leaves a triangle or a plane)
+constexpr uint32_t SRC_SPECIAL = 0xFFFFFFF0u;   // SRC_NONE, SRC_INVALID: no flag bits to read
 constexpr uint32_t SRC_PRIM_MASK = 0x0FFFFFFFu; // primitive index of such a src (rt_scene_upload limits primitives to 2^28)
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
 constexpr uint32_t SMETA_HAS_UV = 0x80000000u;
@@ -44,8 +46,11 @@ static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 //   a = (o.x, o.y, o.z, d.x)
 //   b = (d.y, d.z, bits(src prim code), bits(path id))      -- a,b: all the closest-hit kernel reads
 //   c = (throughput.r, .g, .b, bits(rng state))
-//   e = two words per slot, touched only by rays with SRC_SELF_BIT: the f64 origin (x, y | z, 0) of which `a` holds the
-//       f32 rounding -- whether such a ray re-hits its triangle AGAIN depends on the last bits of that point
+//   e = two words per slot, touched only by rays with SRC_E_BIT (they leave a triangle or a plane, scenes with triangles
+//       only): the f64 origin (x, y | z, 0) of which `a` holds the f32 rounding.  Whether a ray re-hits the triangle it
+//       lands on depends on the last bits of its origin (see tri_hit_ref): a point of a plane y = -0.6 has y = -0.6 to
+//       within an ulp of f64 in the reference, and an f32 rounding of it with random low bits gave 0.54 instead of
+//       0.34 as the re-hit rate of one test triangle
 struct RayQueue {
     float4* a;
     float4* b;
@@ -83,6 +88,7 @@ struct DevScene {
     uint32_t n_tris;          // triangles among the primitives (0: k_shade runs its variant without the f64 triangle arithmetic)
     const float4* planes;     // 2 x float4 per plane: (c.xyz, bits(gid)), (n.xyz, bits(material))
     const int32_t* plane_object;
+    const double* planes64;   // 6 doubles per plane: centre, normal as given (the reference's own operands of intersections.rs:84-95)
     uint32_t n_planes;
     const float4* materials;  // 2 x float4 per material: (r,g,b,param), bits(type, texture, 0, 0)
     const int4* textures;     // (texel offset, width, height, 0)

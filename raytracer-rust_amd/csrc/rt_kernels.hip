@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             B = q.b[ray];
                         }
                         src = __float_as_uint(B.z);
+                        if (src < SRC_SPECIAL) src &= ~SRC_E_BIT;   // (k_shade's business: the ray carries its f64 origin)
                         if (src == SRC_INVALID) {
                             hits[ray] = make_float2(-1.f, __uint_as_float(HIT_INVALID));   // padding slot
                         } else if ((src >> 30) == 1u) {
@@ -787,7 +788,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
     for (; i < n_pad; i += stride) {   // block-uniform trip count
         bool emit = false;       // continue with a scattered ray
         bool fire = false;       // spawn shadow rays
-        bool on_tri = false;     // the hit is on a triangle: p64 is its f64 hit point
+        bool on_tri = false;     // the hit is on a triangle
+        bool has_p64 = false;    // ... or on a plane (scenes with triangles): p64 is the f64 hit point, the rays that leave carry it
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         d3 p64 = mkd(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
@@ -820,11 +822,38 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 f3 nrm;
                 int mat;
                 float u = 0.f, v = 0.f;
+                // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
+                // that left a triangle or a plane (SRC_E_BIT), dithered f32 values otherwise (rays leaving spheres).
+                auto ray64 = [&](d3& o64, d3& d64) {
+                    dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
+                    if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
+                    else if (src < SRC_SPECIAL && (src & SRC_E_BIT)) { const double2 e0 = qi.e[2 * (size_t)i], e1 = qi.e[2 * (size_t)i + 1]; o64 = mkd(e0.x, e0.y, e1.x); }
+                    else o64 = dither64(o, dh);
+                    d64 = dither64(d, dh);
+                };
                 if (code & HIT_PLANE_BIT) {
-                    const float4 P1 = sc.planes[2 * (code & ~HIT_PLANE_BIT) + 1];
+                    const uint32_t pl = code & ~HIT_PLANE_BIT;
+                    const float4 P1 = sc.planes[2 * pl + 1];
                     nrm = mk(P1.x, P1.y, P1.z);                                            // intersections.rs:96 (as given)
                     mat = __float_as_int(P1.w);
-                    p = at_ref(o, d, t);                                                   // raytrace.rs:40-42
+                    if (TRIS) {
+                        // intersections.rs:84-95 in f64 on the reference's operands: the point a ray leaves a plane from is
+                        // ON it to an ulp of f64 (e.g. y = -0.6 exactly for 98.7 % of the rays, one ulp off for the rest), and
+                        // the re-hit rate of the triangle such a ray lands on depends on that (see RayQueue::e)
+#pragma clang fp contract(off)
+                        const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)pl;
+                        const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
+                        d3 o64, d64;
+                        ray64(o64, d64);
+                        const double dot_nd = n64.x * d64.x + n64.y * d64.y + n64.z * d64.z;
+                        const d3 co = sub_ref(c64, o64);
+                        const double t64 = (co.x * n64.x + co.y * n64.y + co.z * n64.z) / dot_nd;
+                        p64 = at_ref(o64, d64, t64);
+                        p = mk((float)p64.x, (float)p64.y, (float)p64.z);
+                        has_p64 = true;
+                    } else {
+                        p = at_ref(o, d, t);                                               // raytrace.rs:40-42
+                    }
                 } else {
                     // one 96-byte shading record per primitive
                     const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)code;
@@ -838,17 +867,14 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
                         const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
-                        dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
-                        d3 o64;
-                        if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
-                        else if ((src >> 30) == 1u) { const double2 e0 = qi.e[2 * (size_t)i], e1 = qi.e[2 * (size_t)i + 1]; o64 = mkd(e0.x, e0.y, e1.x); }
-                        else o64 = dither64(o, dh);
-                        const d3 d64 = dither64(d, dh);
+                        d3 o64, d64;
+                        ray64(o64, d64);
                         double t0, a, b;
                         tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                         p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
                         p = mk((float)p64.x, (float)p64.y, (float)p64.z);
                         on_tri = true;
+                        has_p64 = true;
                         if (sw & SMETA_HAS_UV) {                                           // intersections.rs:177-183
                             const float* uv = sc.uvs + 6 * (size_t)sc.meta[code].w;
                             const double c = 1.0 - a - b;
@@ -918,19 +944,18 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         // A ray that leaves a triangle: does it re-hit that triangle at t ~ 0?  (intersections.rs:166 has no epsilon;
         // see tri_hit_ref.)  The reference's f64 test on the f64 hit point; the verdict travels in the src word.
         auto leaves_src = [&](f3 dir_out, uint32_t& src_out) -> bool {
-            src_out = code;
+            src_out = has_p64 ? (code | SRC_E_BIT) : code;
             if (!TRIS || !on_tri) return false;
             const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
             const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
             const d3 nd64 = dither64(dir_out, dh);
             double t1, a1, b1;
             if (!tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1)) return false;
-            src_out = code | SRC_SELF_BIT;
+            src_out = code | SRC_SELF_BIT | SRC_E_BIT;
             return true;
         };
         uint32_t src_next = code;
-        bool self_next = false;
-        if (!last && emit) self_next = leaves_src(ndir, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
+        if (!last && emit) (void)leaves_src(ndir, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
         if (RT_SHADE_PREFETCH) {
             const uint64_t j = (uint64_t)i + stride;
             if (j < n) load_round((uint32_t)j);
@@ -941,11 +966,10 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             if (emit) {
                 if (slot < capacity) {
                     const uint32_t src_out = src_next;
-                    const bool self = self_next;
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
                     qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
-                    if (self) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
+                    if (TRIS && has_p64) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -960,11 +984,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const float4 Lp = sc.lights[l];
                     const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
                     uint32_t src_out;
-                    const bool self = leaves_src(sd, src_out);
+                    (void)leaves_src(sd, src_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
                     qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pcg_hash(rng + 0x9E3779B9u * (l + 1u))));
-                    if (self) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
+                    if (TRIS && has_p64) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
                 }
             }
         }

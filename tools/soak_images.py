@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Statistical soak of the shading path: random small scenes with every material, emitters (= lights, so the last-bounce
+light sampling and its shadow generations run), a plane and a random mesh; the device at 4096 spp against two oracle renders
+(256 spp each, different seeds).  Per scene:
+  gain  = PSNR(device, mean of the two oracle renders) - PSNR(oracle A, oracle B)   (expected ~ +6 dB: the device's own noise
+          is negligible, so its distance to the mean is sigma/sqrt(2) against sigma*sqrt(2) between the two)
+  z     = bias of the frame's mean radiance in units of its standard error (from the A-B differences)
+python tools/soak_images.py <first seed> <last seed>; exits non-zero if a scene has gain < 3 dB or |z| > 6."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from oracle import oracle_py as O
+rt = importlib.import_module("raytracer-rust_amd")
+W, H = 48, 36
+CAM = dict(eye=[0.0, 1.0, 6.0], look_at=[0.0, 0.3, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)
+
+
+def material(rng, allow_emissive):
+    k = rng.integers(0, 5 if allow_emissive else 4)
+    c = [float(x) for x in rng.uniform(0.2, 0.95, size=3)]
+    if k == 0 or k == 3:
+        return dict(type="Lambertian", albedo=c)
+    if k == 1:
+        return dict(type="Metal", albedo=c, fuzziness=float(rng.choice([0.0, 0.1, 0.5, 1.0])))
+    if k == 2:
+        return dict(type="Dieletrics", tint=[1.0, 1.0, 1.0] if rng.random() < 0.5 else c, refraction_index=float(rng.uniform(1.1, 2.0)))
+    return dict(type="Emissive", color=[float(x) for x in rng.uniform(0.5, 3.0, size=3)])
+
+
+def scene(seed):
+    rng = np.random.default_rng(seed)
+    objs, n_em = [], 0
+    for k in range(int(rng.integers(3, 11))):
+        m = material(rng, n_em < 3)
+        n_em += m["type"] == "Emissive"
+        objs.append(dict(type="Sphere", center=[float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-0.3, 2.0)), float(rng.uniform(-3.0, 2.0))],
+                         radius=float(rng.uniform(0.2, 0.9)), material=m))
+    m = material(rng, n_em < 3)
+    n_em += m["type"] == "Emissive"
+    if m["type"] == "Dieletrics":
+        m = dict(type="Lambertian", albedo=[0.5, 0.5, 0.5])
+    objs.append(dict(type="Plane", center=[0.0, -0.6, 0.0], normal=[0.0, 1.0, 0.0], material=m))
+    if rng.random() < 0.7:
+        nt = int(rng.integers(10, 200))
+        centre = rng.uniform(-2.0, 2.0, size=(nt, 1, 3)) * np.array([1.2, 0.6, 1.0]) + np.array([0.0, 0.8, -1.0])
+        verts = (centre + 0.5 * rng.normal(size=(nt, 3, 3))).reshape(-1, 3)
+        mm = material(rng, n_em < 3)
+        if mm["type"] == "Dieletrics":
+            mm = dict(type="Metal", albedo=[0.8, 0.8, 0.8], fuzziness=0.2)
+        objs.append(dict(type="Mesh", verts=verts, tris=np.arange(3 * nt).reshape(nt, 3), materials=[mm]))
+    bg = [float(x) for x in rng.uniform(0.0, 1.0, size=3)] if rng.random() < 0.8 else [0.0, 0.0, 0.0]
+    return objs, bg, int(rng.integers(2, 9))
+
+
+def main():
+    ctx = rt.Context(0)
+    worst_gain, worst_z, bad = 99.0, 0.0, 0
+    for seed in range(int(sys.argv[1]), int(sys.argv[2]) + 1):
+        objs, bg, depth = scene(seed)
+        ctx.upload(rt.Scene.from_objects(W, H, bg, CAM, objs))
+        osc = O.OracleScene.from_dict(dict(width=W, height=H, background=bg, camera=CAM, objects=[
+            (dict(type="Mesh", materials=o["materials"], mesh=dict(verts_np=o["verts"], tris_np=o["tris"], tri_mat_np=np.zeros(len(o["tris"]), np.int64)))
+             if o["type"] == "Mesh" else o) for o in objs]))
+        t = time.time()
+        A = osc.render(mode="jitter", N=16, depth=depth, seed=2 * seed + 1)["sum"] / 256.0
+        B = osc.render(mode="jitter", N=16, depth=depth, seed=2 * seed + 2)["sum"] / 256.0
+        t_or = time.time() - t
+        try:
+            acc, _ = ctx.render_image(rt.RenderParams("jitter:64", depth=depth, seed=seed))
+        except rt.RtError as e:
+            print("seed %d: %s" % (seed, e), flush=True)     # dropped shadow rays (several lights): reported by design
+            continue
+        D = acc.astype(np.float64) / 4096.0
+        g = lambda x: np.sqrt(np.minimum(np.maximum(x, 0.0), 1.0))          # the reference's gamma and clamp (raytrace.rs:144-150)
+        psnr = lambda a, b: 10 * np.log10(1.0 / max(np.mean((g(a) - g(b)) ** 2), 1e-12))
+        gain = psnr(D, 0.5 * (A + B)) - psnr(A, B)
+        v = np.mean((A - B) ** 2) / 2.0
+        z = (D.mean() - 0.5 * (A + B).mean()) / max(np.sqrt(v / (2.0 * A.size)), 1e-12)
+        n_light = sum(1 for o in objs if (o.get("material") or o["materials"][0])["type"] == "Emissive")
+        flag = "" if (gain >= 3.0 and abs(z) <= 6.0) else "   <-- CHECK"
+        bad += bool(flag)
+        worst_gain, worst_z = min(worst_gain, gain), max(worst_z, abs(z))
+        print("seed %4d: %2d objects, %d lights, depth %d: oracle A-B %.1f dB, device gain %+.1f dB, z %+.2f (%.1f s oracle)%s" %
+              (seed, len(objs), n_light, depth, psnr(A, B), gain, z, t_or, flag), flush=True)
+    print("worst gain %.2f dB, worst |z| %.2f, %d flagged" % (worst_gain, worst_z, bad))
+    sys.exit(1 if bad else 0)
+
+
+main()
