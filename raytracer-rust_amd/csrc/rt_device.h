@@ -46,16 +46,19 @@ static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 //   a = (o.x, o.y, o.z, d.x)
 //   b = (d.y, d.z, bits(src prim code), bits(path id))      -- a,b: all the closest-hit kernel reads
 //   c = (throughput.r, .g, .b, bits(rng state))
-//   e = two words per slot, touched only by rays with SRC_E_BIT (they leave a triangle or a plane, scenes with triangles
-//       only): the f64 origin (x, y | z, 0) of which `a` holds the f32 rounding.  Whether a ray re-hits the triangle it
-//       lands on depends on the last bits of its origin (see tri_hit_ref): a point of a plane y = -0.6 has y = -0.6 to
-//       within an ulp of f64 in the reference, and an f32 rounding of it with random low bits gave 0.54 instead of
-//       0.34 as the re-hit rate of one test triangle
+//   e = one word per slot, touched only by rays with SRC_E_BIT (in scenes with triangles: every ray but the primary ones): the
+//       low 29 mantissa bits of the x, y, z of the ray's f64 origin, whose sign, exponent and upper 23 mantissa bits are the
+//       f32 origin in `a` (truncated, not rounded, for these rays).  Whether a ray re-hits the triangle it lands on depends
+//       on the last bits of its origin (see tri_hit_ref), so in such scenes every hit point is the reference's own f64
+//       function of the ray (plane: intersections.rs:84-95, sphere: :42-68, triangle: :153-172) and travels on exactly:
+//       an f32 rounding with random low bits gave 0.54 instead of 0.34 as the re-hit rate of a triangle behind a mirror
+//       plane at y = -0.6 (a point of that plane has y = -0.6 to an ulp of f64 in the reference), and +4 ... +11 % on
+//       axis-aligned boxes seen through a glass sphere
 struct RayQueue {
     float4* a;
     float4* b;
     float4* c;
-    double2* e;
+    uint4* e;
 };
 
 // Primitive record, 48 bytes = 3 x float4, stored in BVH leaf order.

@@ -302,6 +302,23 @@ __device__ __forceinline__ d3 dither64(f3 v, uint32_t& h) {
     return r;
 }
 
+// An f64 coordinate as (f32 with the same sign, exponent and upper 23 mantissa bits, the 29 mantissa bits below): the form in
+// which a ray's f64 origin travels in the queue (RayQueue::e).  Outside the range of normal f32 numbers (|v| < 2^-126: a
+// coordinate that is exactly 0, mostly) the f32 rounding stands alone, marked by lo = ~0.
+__device__ __forceinline__ void split64(double v, float& hi, uint32_t& lo) {
+    const uint32_t hw = (uint32_t)__double2hiint(v), lw = (uint32_t)__double2loint(v);
+    const uint32_t e = (hw >> 20) & 0x7FFu;
+    if (e <= 896u || e >= 1151u) { hi = (float)v; lo = 0xFFFFFFFFu; return; }
+    hi = __uint_as_float((hw & 0x80000000u) | ((e - 896u) << 23) | ((hw & 0xFFFFFu) << 3) | (lw >> 29));
+    lo = lw & 0x1FFFFFFFu;
+}
+__device__ __forceinline__ double join64(float hi, uint32_t lo) {
+    if (lo == 0xFFFFFFFFu) return (double)hi;
+    const uint32_t fb = __float_as_uint(hi);
+    const uint32_t hw = (fb & 0x80000000u) | ((((fb >> 23) & 0xFFu) + 896u) << 20) | ((fb >> 3) & 0xFFFFFu);
+    return __hiloint2double((int)hw, (int)((fb << 29) | lo));
+}
+
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
 #ifndef RT_REFILL
 #define RT_REFILL 32
@@ -740,6 +757,9 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 #ifndef RT_SHADE_PREFETCH
 #define RT_SHADE_PREFETCH 1
 #endif
+#ifndef RT_SPHERE_REF64
+#define RT_SPHERE_REF64 1
+#endif
 #ifndef RT_SHADE_GRID_MUL
 #define RT_SHADE_GRID_MUL 2u
 #endif
@@ -827,7 +847,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 auto ray64 = [&](d3& o64, d3& d64) {
                     dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
                     if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
-                    else if (src < SRC_SPECIAL && (src & SRC_E_BIT)) { const double2 e0 = qi.e[2 * (size_t)i], e1 = qi.e[2 * (size_t)i + 1]; o64 = mkd(e0.x, e0.y, e1.x); }
+                    else if (src < SRC_SPECIAL && (src & SRC_E_BIT)) { const uint4 E = qi.e[i]; o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z)); }
                     else o64 = dither64(o, dh);
                     d64 = dither64(d, dh);
                 };
@@ -883,8 +903,36 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         }
                     } else {
                         const float4 r0 = rec[1], r1 = rec[2];
-                        p = at_ref(o, d, t);                                               // intersections.rs:68
-                        nrm = sphere_normal(r0, r1, o, d, t);                              // intersections.rs:69
+                        if (TRIS && RT_SPHERE_REF64) {
+                            // intersections.rs:42-69 in f64, operation by operation: in scenes with triangles every hit point
+                            // is the reference's own f64 function of the ray, because the rays that leave it carry it as
+                            // their origin and the last bits of an origin decide what happens on the triangle it reaches
+#pragma clang fp contract(off)
+                            const double cx = __hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+                            const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+                            const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+                            const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+                            d3 o64, d64;
+                            ray64(o64, d64);
+                            const d3 oc = sub_ref(o64, mkd(cx, cy, cz));
+                            const double qa = d64.x * d64.x + d64.y * d64.y + d64.z * d64.z;
+                            const double qb = 2.0 * (d64.x * oc.x + d64.y * oc.y + d64.z * oc.z);
+                            const double qc = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - rad * rad;
+                            double disc = qb * qb - 4.0 * qa * qc;
+                            disc = sqrt(disc > 0.0 ? disc : 0.0);
+                            // intersections.rs:54-63: the nearer root if it is above 1e-5, else the farther one (the second
+                            // division only then)
+                            double t64 = (-qb - disc) / (2.0 * qa);
+                            if (!(t64 > 1e-5)) t64 = (-qb + disc) / (2.0 * qa);
+                            p64 = at_ref(o64, d64, t64);
+                            p = mk((float)p64.x, (float)p64.y, (float)p64.z);
+                            const double ir = 1.0 / rad;    // (the normal is rounded to f32: one reciprocal instead of the reference's three divisions)
+                            nrm = mk((float)((p64.x - cx) * ir), (float)((p64.y - cy) * ir), (float)((p64.z - cz) * ir));
+                            has_p64 = true;
+                        } else {
+                            p = at_ref(o, d, t);                                           // intersections.rs:68
+                            nrm = sphere_normal(r0, r1, o, d, t);                          // intersections.rs:69
+                        }
                     }
                 }
                 const float4 M0 = sc.materials[2 * mat], M1 = sc.materials[2 * mat + 1];
@@ -954,6 +1002,10 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             src_out = code | SRC_SELF_BIT | SRC_E_BIT;
             return true;
         };
+        uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
+        if (TRIS && has_p64) {   // the f64 hit point as (f32 origin, low bits): see RayQueue::e
+            split64(p64.x, p.x, p_lo.x); split64(p64.y, p.y, p_lo.y); split64(p64.z, p.z, p_lo.z);
+        }
         uint32_t src_next = code;
         if (!last && emit) (void)leaves_src(ndir, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
         if (RT_SHADE_PREFETCH) {
@@ -969,7 +1021,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
                     qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
-                    if (TRIS && has_p64) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
+                    if (TRIS && has_p64) qo.e[slot] = p_lo;
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -988,7 +1040,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
                     qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pcg_hash(rng + 0x9E3779B9u * (l + 1u))));
-                    if (TRIS && has_p64) { qo.e[2 * (size_t)slot] = make_double2(p64.x, p64.y); qo.e[2 * (size_t)slot + 1] = make_double2(p64.z, 0.0); }
+                    if (TRIS && has_p64) qo.e[slot] = p_lo;
                 }
             }
         }
