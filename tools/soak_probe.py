@@ -11,7 +11,7 @@ exec(compile(src, "soak_images", "exec"), ns)
 rt, O, W, H, CAM = ns["rt"], ns["O"], ns["W"], ns["H"], ns["CAM"]
 seed = int(sys.argv[1])
 SEED0 = int(os.environ.get("PROBE_SEED0", "100"))     # other oracle / device random streams
-objs, bg, depth = ns["scene"](seed)
+objs, bg, depth = (ns["room"] if os.environ.get("SOAK_ROOM") else ns["scene"])(seed)
 if len(sys.argv) > 2:
     depth = int(sys.argv[2])
 drop = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []      # object indices to leave out
