@@ -991,9 +991,13 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         }
         // A ray that leaves a triangle: does it re-hit that triangle at t ~ 0?  (intersections.rs:166 has no epsilon;
         // see tri_hit_ref.)  The reference's f64 test on the f64 hit point; the verdict travels in the src word.
-        auto leaves_src = [&](f3 dir_out, uint32_t& src_out) -> bool {
+        // rng_out: the rng word the emitted ray carries.  The verdict is formed on the very f64 ray the next k_shade will form
+        // from the queue words (same origin bits, same dither bits of the direction: the next launch derives them from
+        // that word), as in the reference, where the verdict IS the next intersection.
+        auto leaves_src = [&](f3 dir_out, uint32_t rng_out, uint32_t& src_out) -> bool {
             src_out = has_p64 ? (code | SRC_E_BIT) : code;
             if (!TRIS || !on_tri) return false;
+            uint32_t dh = pcg_hash(rng_out ^ 0x68E31DA4u);
             const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
             const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
             const d3 nd64 = dither64(dir_out, dh);
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             split64(p64.x, p.x, p_lo.x); split64(p64.y, p.y, p_lo.y); split64(p64.z, p.z, p_lo.z);
         }
         uint32_t src_next = code;
-        if (!last && emit) (void)leaves_src(ndir, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
+        if (!last && emit) (void)leaves_src(ndir, rng, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
         if (RT_SHADE_PREFETCH) {
             const uint64_t j = (uint64_t)i + stride;
             if (j < n) load_round((uint32_t)j);
@@ -1036,10 +1040,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const float4 Lp = sc.lights[l];
                     const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
                     uint32_t src_out;
-                    (void)leaves_src(sd, src_out);
+                    const uint32_t rng_l = pcg_hash(rng + 0x9E3779B9u * (l + 1u));
+                    (void)leaves_src(sd, rng_l, src_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
                     qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
-                    qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pcg_hash(rng + 0x9E3779B9u * (l + 1u))));
+                    qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng_l));
                     if (TRIS && has_p64) qo.e[slot] = p_lo;
                 }
             }

@@ -38,7 +38,7 @@ def scene(seed):
                          radius=float(rng.uniform(0.2, 0.9)), material=m))
     m = material(rng, n_em < 3)
     n_em += m["type"] == "Emissive"
-    if m["type"] == "Dieletrics":
+    if m["type"] == "Dieletrics" and not os.environ.get("SOAK_GLASS_MESH"):
         m = dict(type="Lambertian", albedo=[0.5, 0.5, 0.5])
     # the ground: usually level at a height that is no round number, sometimes tilted; sometimes a wall behind the scene too
     ground_y = float(rng.choice([-0.6, -0.5, 0.0, -1.0, -0.37]))
@@ -67,7 +67,9 @@ def scene(seed):
             verts = np.array(vs)
             nt = len(verts) // 3
         mm = material(rng, n_em < 3)
-        if mm["type"] == "Dieletrics":
+        if os.environ.get("SOAK_GLASS_MESH") and rng.random() < 0.6:      # glass meshes and glass ground: refraction through triangles and planes
+            mm = dict(type="Dieletrics", tint=[float(x) for x in rng.uniform(0.6, 1.0, size=3)], refraction_index=float(rng.uniform(1.1, 1.9)))
+        elif mm["type"] == "Dieletrics":
             mm = dict(type="Metal", albedo=[0.8, 0.8, 0.8], fuzziness=0.2)
         objs.append(dict(type="Mesh", verts=verts, tris=np.arange(3 * nt).reshape(nt, 3), materials=[mm]))
     bg = [float(x) for x in rng.uniform(0.0, 1.0, size=3)] if rng.random() < 0.8 else [0.0, 0.0, 0.0]
