@@ -126,7 +126,7 @@ void free_scene(rt_context* ctx) {
 
 void free_state(rt_context* ctx) {
     for (int k = 0; k < 2; ++k) {
-        (void)hipFree(ctx->q[k].a); (void)hipFree(ctx->q[k].b); (void)hipFree(ctx->q[k].c); (void)hipFree(ctx->q[k].e);
+        (void)hipFree(ctx->q[k].a); (void)hipFree(ctx->q[k].b); (void)hipFree(ctx->q[k].c); (void)hipFree(ctx->q[k].e); (void)hipFree(ctx->q[k].f);
         ctx->q[k] = RayQueue{};
     }
     (void)hipFree(ctx->hits); ctx->hits = nullptr;
@@ -143,6 +143,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].b, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].c, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].e, (size_t)capacity * sizeof(uint4)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].f, (size_t)capacity * sizeof(uint2)));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
@@ -243,6 +244,7 @@ struct FlatScene {
     std::vector<int4> meta, textures;
     std::vector<float> uvs;
     std::vector<int32_t> plane_obj;
+    std::vector<double> mat_param64; // the material parameters as given (f64)
     std::vector<double> planes64;    // centre, normal of every plane as given (f64)
     std::vector<uchar4> texels;
     uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0, n_tris = 0;
@@ -448,6 +450,7 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
     mats.assign((size_t)d->n_materials * 2, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         mats[2 * i] = make_float4((float)d->mat_rgb[3 * i], (float)d->mat_rgb[3 * i + 1], (float)d->mat_rgb[3 * i + 2], (float)d->mat_param[i]);
+        f.mat_param64.push_back(d->mat_param[i]);
         int32_t w[4] = {d->mat_type[i], d->mat_texture ? d->mat_texture[i] : -1, 0, 0};
         std::memcpy(&mats[2 * i + 1], w, 16);
     }
@@ -495,7 +498,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     free_scene(ctx);
     DevScene sc{};
     if (upload(ctx, f.nodes, &sc.nodes) || upload(ctx, f.prims, &sc.prims) || upload(ctx, f.meta, &sc.meta) || upload(ctx, f.smeta, &sc.smeta) ||
-        upload(ctx, f.uvs, &sc.uvs) || upload(ctx, f.planes, &sc.planes) || upload(ctx, f.plane_obj, &sc.plane_object) || upload(ctx, f.planes64, &sc.planes64) ||
+        upload(ctx, f.uvs, &sc.uvs) || upload(ctx, f.planes, &sc.planes) || upload(ctx, f.plane_obj, &sc.plane_object) || upload(ctx, f.planes64, &sc.planes64) || upload(ctx, f.mat_param64, &sc.mat_param64) ||
         upload(ctx, f.mats, &sc.materials) || upload(ctx, f.textures, &sc.textures) || upload(ctx, f.texels, &sc.texels) ||
         upload(ctx, f.lights, &sc.lights)) {
         free_scene(ctx);
@@ -569,7 +572,7 @@ static inline size_t align256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 // bytes of static scratch a pass of `paths` paths needs (rtamd.h: RT_NOALLOC_SCRATCH_BYTES)
 static size_t noalloc_bytes(uint32_t paths, uint32_t per_path) {
     const size_t cap = (size_t)paths * per_path;
-    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + 2 * align256(cap * sizeof(uint4)) +
+    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + 2 * align256(cap * sizeof(uint4)) + 2 * align256(cap * sizeof(uint2)) +
            align256(cap * sizeof(float2)) + align256((size_t)paths * sizeof(float4));
 }
 
@@ -617,6 +620,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             ws.q[k].b = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].c = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].e = reinterpret_cast<uint4*>(carve(cap * sizeof(uint4)));
+            ws.q[k].f = reinterpret_cast<uint2*>(carve(cap * sizeof(uint2)));
         }
         ws.hits = reinterpret_cast<float2*>(carve(cap * sizeof(float2)));
         ws.radiance = reinterpret_cast<float4*>(carve((size_t)paths * sizeof(float4)));

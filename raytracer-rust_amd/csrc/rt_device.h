@@ -13,6 +13,7 @@ constexpr uint32_t SRC_INVALID = 0xFFFFFFFDu; // padding slot of a border tile: 
 constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t SRC_SELF_BIT = 0x40000000u;  // src = SRC_SELF_BIT | triangle: the ray re-hits the triangle it starts on at t ~ 0 (decided by k_shade, see there)
 constexpr uint32_t SRC_E_BIT = 0x20000000u;     // src | SRC_E_BIT (src below SRC_SPECIAL): queue word e holds the ray's f64 origin (it leaves a triangle or a plane)
+constexpr uint32_t SRC_D_BIT = 0x10000000u;     // ... and e.w, f hold its f64 direction (it left a mirror or a dielectric); only with SRC_E_BIT
 constexpr uint32_t SRC_SPECIAL = 0xFFFFFFF0u;   // SRC_NONE, SRC_INVALID: no flag bits to read
 constexpr uint32_t SRC_PRIM_MASK = 0x0FFFFFFFu; // primitive index of such a src (rt_scene_upload limits primitives to 2^28)
 constexpr uint32_t PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u;
@@ -54,11 +55,17 @@ static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 //       an f32 rounding with random low bits gave 0.54 instead of 0.34 as the re-hit rate of a triangle behind a mirror
 //       plane at y = -0.6 (a point of that plane has y = -0.6 to an ulp of f64 in the reference), and +4 ... +11 % on
 //       axis-aligned boxes seen through a glass sphere
+//   f = with e.w: the same for the x (e.w), y, z (f) of the DIRECTION of a ray that left a mirror or a dielectric (SRC_D_BIT),
+//       which the reference computes from the arriving ray alone (materials.rs:119-183): its last bits are tied to that
+//       ray's (reflecting off an axis-aligned face flips one sign and changes nothing else), and that decides what the
+//       ray does on the next triangle.  Diffuse and fuzzy bounces add a random vector: their directions stay f32 and get
+//       random low bits where they enter f64 arithmetic
 struct RayQueue {
     float4* a;
     float4* b;
     float4* c;
     uint4* e;
+    uint2* f;
 };
 
 // Primitive record, 48 bytes = 3 x float4, stored in BVH leaf order.
@@ -91,6 +98,7 @@ struct DevScene {
     uint32_t n_tris;          // triangles among the primitives (0: k_shade runs its variant without the f64 triangle arithmetic)
     const float4* planes;     // 2 x float4 per plane: (c.xyz, bits(gid)), (n.xyz, bits(material))
     const int32_t* plane_object;
+    const double* mat_param64; // the material parameter (fuzziness / refraction index) as given
     const double* planes64;   // 6 doubles per plane: centre, normal as given (the reference's own operands of intersections.rs:84-95)
     uint32_t n_planes;
     const float4* materials;  // 2 x float4 per material: (r,g,b,param), bits(type, texture, 0, 0)

@@ -280,6 +280,34 @@ __device__ __forceinline__ f3 at_ref(f3 o, f3 d, float t) {   // the same in f32
 #pragma clang fp contract(off)
     return mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
+// vec3.rs in f64, operation by operation (no contraction): what the specular scatter of k_shade is made of
+__device__ __forceinline__ double dot_ref(d3 a, d3 b) {          // vec3.rs:81-83
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ d3 neg_ref(d3 a) { return mkd(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 cross_ref(d3 a, d3 b) {            // vec3.rs:104-110
+#pragma clang fp contract(off)
+    return mkd(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ d3 normalized_ref(d3 v) {             // vec3.rs:115-121
+#pragma clang fp contract(off)
+    const double n = sqrt(dot_ref(v, v));
+    if (n != 0.0) return mkd(v.x / n, v.y / n, v.z / n);
+    return v;
+}
+__device__ __forceinline__ d3 reflect_ref(d3 v, d3 n) {          // vec3.rs:129-131
+#pragma clang fp contract(off)
+    const double k = 2.0 * dot_ref(v, n);
+    return mkd(v.x - n.x * k, v.y - n.y * k, v.z - n.z * k);
+}
+__device__ __forceinline__ d3 refract_ref(d3 dir, d3 n, double ratio) {   // materials.rs:105-110
+#pragma clang fp contract(off)
+    const double c = fmin(dot_ref(n, neg_ref(dir)), 1.0);
+    const d3 perp = mkd((dir.x + n.x * c) * ratio, (dir.y + n.y * c) * ratio, (dir.z + n.z * c) * ratio);
+    const double k = -sqrt(fabs(1.0 - dot_ref(perp, perp)));
+    return mkd(perp.x + n.x * k, perp.y + n.y * k, perp.z + n.z * k);
+}
 // one iteration of the loop of intersections.rs:148-186: a = Ma / M, b = Mb / M, t = -(Mt / M); true = the candidate
 // passes the reject test of line 166 (a NaN candidate, M == 0, is not taken: the reference takes it only while it
 // has no other hit, and a ray parallel to the triangle it starts on leaves it)
@@ -322,6 +350,9 @@ __device__ __forceinline__ double join64(float hi, uint32_t lo) {
     return __hiloint2double((int)hw, (int)((fb << 29) | lo));
 }
 
+#ifndef RT_DIR_REF64
+#define RT_DIR_REF64 1   // scenes with triangles: mirror and dielectric bounces off triangles and planes in f64, their directions carried exactly (RayQueue::f); 2: off spheres too
+#endif
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
 #ifndef RT_REFILL
 #define RT_REFILL 32
@@ -451,7 +482,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             B = q.b[ray];
                         }
                         src = __float_as_uint(B.z);
-                        if (src < SRC_SPECIAL) src &= ~SRC_E_BIT;   // (k_shade's business: the ray carries its f64 origin)
+                        if (src < SRC_SPECIAL) src &= ~(SRC_E_BIT | SRC_D_BIT);   // (k_shade's business: the ray carries its f64 origin / direction)
                         if (src == SRC_INVALID) {
                             hits[ray] = make_float2(-1.f, __uint_as_float(HIT_INVALID));   // padding slot
                         } else if ((src >> 30) == 1u) {
@@ -816,6 +847,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         d3 p64 = mkd(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
+        bool dir_exact = false;  // the scattered direction is the reference's f64 one: ndir holds its upper bits, d_lo the lower ones (RayQueue::f)
+        uint32_t d_lo_x = 0, d_lo_y = 0, d_lo_z = 0;
         if (i < n) {
             if (!RT_SHADE_PREFETCH) load_round(i);
             const float4 A = nA;
@@ -846,13 +879,24 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 int mat;
                 float u = 0.f, v = 0.f;
                 // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
-                // that left a triangle or a plane (SRC_E_BIT), dithered f32 values otherwise (rays leaving spheres).
-                auto ray64 = [&](d3& o64, d3& d64) {
+                // that left a triangle, a plane or a sphere (SRC_E_BIT), a dithered f32 origin otherwise; the carried f64
+                // direction after a specular bounce (SRC_D_BIT), a dithered f32 direction otherwise.
+                d3 d64 = mkd(0, 0, 0);
+                uint32_t sw = 0;
+                auto ray64 = [&](d3& o64) {
                     dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
+                    const bool carried = it != 0 && src < SRC_SPECIAL && (src & SRC_E_BIT);
+                    uint4 E = make_uint4(0u, 0u, 0u, 0u);
+                    if (carried) E = qi.e[i];
                     if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
-                    else if (src < SRC_SPECIAL && (src & SRC_E_BIT)) { const uint4 E = qi.e[i]; o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z)); }
+                    else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                     else o64 = dither64(o, dh);
-                    d64 = dither64(d, dh);
+                    if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
+                        const uint2 F = qi.f[i];
+                        d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
+                    } else {
+                        d64 = dither64(d, dh);
+                    }
                 };
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
@@ -866,8 +910,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
 #pragma clang fp contract(off)
                         const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)pl;
                         const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
-                        d3 o64, d64;
-                        ray64(o64, d64);
+                        d3 o64;
+                        ray64(o64);
                         const double dot_nd = n64.x * d64.x + n64.y * d64.y + n64.z * d64.z;
                         const d3 co = sub_ref(c64, o64);
                         const double t64 = (co.x * n64.x + co.y * n64.y + co.z * n64.z) / dot_nd;
@@ -881,7 +925,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     // one 96-byte shading record per primitive
                     const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)code;
                     const float4 S = rec[0];
-                    const uint32_t sw = __float_as_uint(S.w);
+                    sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
                     if (TRIS && !(sw & SMETA_SPHERE)) {
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
@@ -890,8 +934,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
                         const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
-                        d3 o64, d64;
-                        ray64(o64, d64);
+                        d3 o64;
+                        ray64(o64);
                         double t0, a, b;
                         tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                         p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
@@ -915,8 +959,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                             const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
                             const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
                             const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
-                            d3 o64, d64;
-                            ray64(o64, d64);
+                            d3 o64;
+                            ray64(o64);
                             const d3 oc = sub_ref(o64, mkd(cx, cy, cz));
                             const double qa = d64.x * d64.x + d64.y * d64.y + d64.z * d64.z;
                             const double qb = 2.0 * (d64.x * oc.x + d64.y * oc.y + d64.z * oc.z);
@@ -940,6 +984,31 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 }
                 const float4 M0 = sc.materials[2 * mat], M1 = sc.materials[2 * mat + 1];
                 const int mtype = __float_as_int(M1.x);
+                // intersection_info.normal as the reference has it, in f64 (only the specular materials ask for it; the
+                // records are read again rather than kept in registers)
+                auto normal64 = [&]() -> d3 {
+#pragma clang fp contract(off)
+                    if (code & HIT_PLANE_BIT) {                                            // intersections.rs:96 (as given)
+                        const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)(code & ~HIT_PLANE_BIT);
+                        return mkd(P64[3], P64[4], P64[5]);
+                    }
+                    const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
+                    if (!(sw & SMETA_SPHERE)) {                                            // intersections.rs:169
+                        const double2 w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                        return normalized_ref(cross_ref(mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x)));
+                    }
+                    const double2 c0 = r64[0], c1 = r64[1];                                // intersections.rs:69
+                    return mkd((p64.x - c0.x) / c1.y, (p64.y - c0.y) / c1.y, (p64.z - c1.x) / c1.y);
+                };
+                // Flat surfaces only: there a specular bounce keeps the arriving ray's bits (the normal is a constant, often
+                // with exact zeros), and the triangles it goes on to are met with directions tied to the one before.  A sphere's
+                // normal (p - c) / r is rounded anew at every hit and mixes into every component, so nothing is carried over;
+                // with RT_DIR_REF64 = 2 spheres take the f64 path too (C5: -8.4 %).
+                const bool exact_bounce = TRIS && RT_DIR_REF64 && (RT_DIR_REF64 > 1 || (code & HIT_PLANE_BIT) || !(sw & SMETA_SPHERE));
+                auto set_exact = [&](d3 nd) {   // Ray::new (raytrace.rs:32-37) has normalised nd
+                    split64(nd.x, ndir.x, d_lo_x); split64(nd.y, ndir.y, d_lo_y); split64(nd.z, ndir.z, d_lo_z);
+                    dir_exact = true;
+                };
                 f3 albedo = mk(M0.x, M0.y, M0.z);
                 bool scattered = false;
                 if (mtype == 4) {                                   // Emissive, materials.rs:80-88
@@ -950,20 +1019,53 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     ndir = normalized(dir);
                     scattered = true;
                 } else if (mtype == 1) {                            // Metal, materials.rs:168-183
-                    const f3 refl = reflect(normalized(d), nrm);
-                    ndir = normalized(refl + random_in_unit_sphere(rng) * M0.w);
-                    scattered = dot(ndir, nrm) > 0.f;               // else None: the path ends black (raytrace.rs:92)
+                    if (exact_bounce && M0.w == 0.f) {
+                        // a mirror: the scattered direction is a function of the ray alone, so it is the reference's own f64
+                        // sequence on the f64 ray and travels on exactly (see RayQueue::f); the fuzz term is +-0
+                        const d3 n64 = normal64();
+                        const d3 nd = normalized_ref(reflect_ref(normalized_ref(d64), n64));
+                        scattered = dot_ref(nd, n64) > 0.0;
+                        set_exact(nd);
+                    } else {
+                        const f3 refl = reflect(normalized(d), nrm);
+                        ndir = normalized(refl + random_in_unit_sphere(rng) * M0.w);
+                        scattered = dot(ndir, nrm) > 0.f;           // else None: the path ends black (raytrace.rs:92)
+                    }
                 } else if (mtype == 2) {                            // Dieletrics, materials.rs:119-153
-                    const bool front = dot(nrm, d) <= 0.f;
-                    const float ratio = front ? 1.0f / M0.w : M0.w;
-                    const f3 nn = front ? nrm : -nrm;
-                    const float cos_theta = fminf(dot(-d, nn), 1.f);
-                    const float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
-                    const bool cannot_refract = ratio * sin_theta > 1.f;
-                    f3 dir = refract(d, nn, ratio);
-                    // the RNG draw is skipped when cannot_refract (short circuit, materials.rs:143-144)
-                    if (cannot_refract || reflectance(cos_theta, ratio) > rng_unit(rng)) dir = reflect(d, nn);
-                    ndir = normalized(dir);
+                    if (exact_bounce) {
+                        // the same in f64 on the f64 ray, normal and refraction index: the direction that leaves is a function
+                        // of the ray alone, and in the reference its last bits are tied to those of the ray that arrived (a
+                        // reflection off an axis-aligned face only flips a sign).  What the ray then does on the triangle it
+                        // reaches depends on that: with f32 directions + random low bits 124 of 600,000 paths through an
+                        // axis-aligned glass box left it at the third interface where the reference has none.
+#pragma clang fp contract(off)
+                        const d3 n64 = normal64();
+                        const double ior = sc.mat_param64[mat];
+                        const bool front = dot_ref(n64, d64) <= 0.0;
+                        const double ratio = front ? 1.0 / ior : ior;
+                        const d3 nn = front ? n64 : neg_ref(n64);
+                        const double cos_theta = fmin(dot_ref(neg_ref(d64), nn), 1.0);
+                        const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                        bool refl = ratio * sin_theta > 1.0;                  // cannot_refract
+                        if (!refl) {                                          // the RNG draw is skipped otherwise (materials.rs:143-144)
+                            double r0 = (1.0 - ratio) / (1.0 + ratio);
+                            r0 = r0 * r0;
+                            const double x = 1.0 - cos_theta, x2 = x * x;
+                            refl = r0 + (1.0 - r0) * (x2 * x2 * x) > (double)rng_unit(rng);
+                        }
+                        set_exact(normalized_ref(refl ? reflect_ref(d64, nn) : refract_ref(d64, nn, ratio)));
+                    } else {
+                        const bool front = dot(nrm, d) <= 0.f;
+                        const float ratio = front ? 1.0f / M0.w : M0.w;
+                        const f3 nn = front ? nrm : -nrm;
+                        const float cos_theta = fminf(dot(-d, nn), 1.f);
+                        const float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+                        const bool cannot_refract = ratio * sin_theta > 1.f;
+                        f3 dir = refract(d, nn, ratio);
+                        // the RNG draw is skipped when cannot_refract (short circuit, materials.rs:143-144)
+                        if (cannot_refract || reflectance(cos_theta, ratio) > rng_unit(rng)) dir = reflect(d, nn);
+                        ndir = normalized(dir);
+                    }
                     scattered = true;
                 } else {                                            // Texture, materials.rs:233-253
                     albedo = texture_albedo(sc, __float_as_int(M1.y), u, v);
@@ -997,24 +1099,26 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         // rng_out: the rng word the emitted ray carries.  The verdict is formed on the very f64 ray the next k_shade will form
         // from the queue words (same origin bits, same dither bits of the direction: the next launch derives them from
         // that word), as in the reference, where the verdict IS the next intersection.
-        auto leaves_src = [&](f3 dir_out, uint32_t rng_out, uint32_t& src_out) -> bool {
-            src_out = has_p64 ? (code | SRC_E_BIT) : code;
+        // exact: dir_out is ndir after a specular bounce, whose f64 value travels with the ray (SRC_D_BIT)
+        auto leaves_src = [&](f3 dir_out, bool exact, uint32_t rng_out, uint32_t& src_out) -> bool {
+            src_out = has_p64 ? (code | SRC_E_BIT | (exact ? SRC_D_BIT : 0u)) : code;
             if (!TRIS || !on_tri) return false;
             uint32_t dh = pcg_hash(rng_out ^ 0x68E31DA4u);
             const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
             const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
-            const d3 nd64 = dither64(dir_out, dh);
+            const d3 nd64 = exact ? mkd(join64(dir_out.x, d_lo_x), join64(dir_out.y, d_lo_y), join64(dir_out.z, d_lo_z)) : dither64(dir_out, dh);
             double t1, a1, b1;
             if (!tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1)) return false;
-            src_out = code | SRC_SELF_BIT | SRC_E_BIT;
+            src_out |= SRC_SELF_BIT;
             return true;
         };
         uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
         if (TRIS && has_p64) {   // the f64 hit point as (f32 origin, low bits): see RayQueue::e
             split64(p64.x, p.x, p_lo.x); split64(p64.y, p.y, p_lo.y); split64(p64.z, p.z, p_lo.z);
         }
+        dir_exact = dir_exact && has_p64 && emit;
         uint32_t src_next = code;
-        if (!last && emit) (void)leaves_src(ndir, rng, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
+        if (!last && emit) (void)leaves_src(ndir, dir_exact, rng, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
         if (RT_SHADE_PREFETCH) {
             const uint64_t j = (uint64_t)i + stride;
             if (j < n) load_round((uint32_t)j);
@@ -1028,7 +1132,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
                     qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
-                    if (TRIS && has_p64) qo.e[slot] = p_lo;
+                    if (TRIS && has_p64) qo.e[slot] = make_uint4(p_lo.x, p_lo.y, p_lo.z, d_lo_x);
+                    if (TRIS && RT_DIR_REF64 && dir_exact) qo.f[slot] = make_uint2(d_lo_y, d_lo_z);
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -1044,7 +1149,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
                     uint32_t src_out;
                     const uint32_t rng_l = pcg_hash(rng + 0x9E3779B9u * (l + 1u));
-                    (void)leaves_src(sd, rng_l, src_out);
+                    (void)leaves_src(sd, false, rng_l, src_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
                     qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng_l));
