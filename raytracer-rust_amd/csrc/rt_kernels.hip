@@ -254,7 +254,8 @@ __device__ __forceinline__ f3 sphere_normal(const float4 r0, const float4 r1, f3
 // whose last bits decide the re-hits that follow.  In scenes with triangles the ORIGIN of every ray is exact: each hit
 // point (plane, sphere, triangle) is computed with the reference's f64 sequence and carried on as the f32 origin plus its
 // 29 lower mantissa bits (RayQueue::e; an f32 origin with random low bits changed the re-hit rate of a triangle behind a
-// mirror plane from 0.34 to 0.54).  DIRECTIONS stay f32; where one enters the f64 sequence its 29 missing mantissa bits
+// mirror plane from 0.34 to 0.54).  DIRECTIONS are exact after a mirror or dielectric bounce off a triangle or a plane
+// (RayQueue::f, see k_shade) and f32 otherwise; where an f32 direction enters the f64 sequence its 29 missing mantissa bits
 // are filled with random bits (dither64): operands with trailing zeros make half of the sequence's products exact and
 // shift the probabilities (0.13 instead of 0.36 on one test triangle), while random low bits are what the reference's
 // own f64 directions carry.  (The same sequence in f32 -- round 1 -- gave
