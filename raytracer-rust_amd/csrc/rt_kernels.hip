@@ -139,16 +139,38 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
 // ---------------------------------------------------------------- closest hit
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct Best {
-    float t;
+    float t;         // scenes with triangles: times 1 + 2 RT_TIE_EPS (see consider)
     uint32_t code;   // HIT_MISS, prim index (leaf order) or HIT_PLANE_BIT | plane
-    uint32_t gid;    // tie-break key
+    uint32_t aux;    // scenes with triangles: a candidate whose f32 t is within RT_TIE_EPS of the best one (HIT_MISS: none);
+                     // scenes without: the scan rank (gid) of the best one, the tie-break key
 };
 
 // scene.rs:43 / intersections.rs:170: strict '>' while scanning in object/triangle order
-// == smallest t, then smallest scan rank.
-__device__ __forceinline__ void consider(Best& best, float t, uint32_t code, uint32_t gid) {
-    if (t < best.t || (t == best.t && gid < best.gid)) {
-        best.t = t; best.code = code; best.gid = gid;
+// == smallest t, then smallest scan rank (gid).
+// Scenes with triangles (tris, wave-uniform): two candidates whose f32 distances agree to RT_TIE_EPS are BOTH reported, the
+// nearer as the hit, the other as the runner-up -- a box that stands exactly on the ground plane, a box on a box.  In the
+// reference the f64 roundings of the two distances decide which surface such a ray meets, ray by ray; the f32 order here
+// says nothing about that, so k_shade evaluates both with the reference's f64 sequences (see there).  The distances are
+// kept times tie_k = 1 + 2 RT_TIE_EPS, so that the node test, which culls against best.t, cannot drop the subtree of a
+// runner-up (one multiplication per accepted candidate instead of one per node step; the hit record carries no distance
+// in such scenes, k_shade forms every one in f64).  Scenes without triangles: tie_k = 1, best.t is the distance itself.
+#ifndef RT_TIE_EPS
+#define RT_TIE_EPS 0x1p-13f
+#endif
+__device__ __forceinline__ uint32_t gid_of(const DevScene& sc, uint32_t code) {
+    return __float_as_uint((code & HIT_PLANE_BIT) ? sc.planes[2 * (size_t)(code & ~HIT_PLANE_BIT)].w : sc.prims[3 * (size_t)code + 2].y);
+}
+__device__ __forceinline__ void consider(bool tris, float tie_k, Best& best, float t, uint32_t code, uint32_t gid) {
+    t *= tie_k;
+    const float gap = t - best.t;                                // (-inf while there is no hit)
+    if (tris) {
+        const bool win = gap < 0.f;
+        const uint32_t other = win ? best.code : code;
+        if (fabsf(gap) <= RT_TIE_EPS * t) best.aux = other;
+        else if (win) best.aux = HIT_MISS;
+        if (win) { best.t = t; best.code = code; }
+    } else if (gap < 0.f || (gap == 0.f && gid < best.aux)) {
+        best.t = t; best.code = code; best.aux = gid;
     }
 }
 
@@ -444,7 +466,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     float idx = 0.f, idy = 0.f, idz = 0.f;
     Best best;
-    best.t = 0.f; best.code = HIT_MISS; best.gid = 0u;
+    const bool tris = sc.n_tris != 0u;                       // wave-uniform: what Best::aux holds, see consider
+    const float tie_k = tris ? 1.f + 2.f * RT_TIE_EPS : 1.f;
+    best.t = 0.f; best.code = HIT_MISS; best.aux = HIT_MISS;
 
     for (;;) {
         // ---------------- refill: idle lanes take the next rays of the wave's range
@@ -489,11 +513,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         } else if ((src >> 30) == 1u) {
                             // the ray re-hits the triangle it starts on at t ~ 1e-16 (k_shade's verdict, see tri_hit_ref):
                             // nothing can be closer, no traversal
-                            hits[ray] = make_float2(0.f, __uint_as_float(src & SRC_PRIM_MASK));
+                            hits[ray] = make_float2(__uint_as_float(HIT_MISS), __uint_as_float(src & SRC_PRIM_MASK));   // (self-hits exist in scenes with triangles only: first word = runner-up, none)
                             if (COUNT) cnt_self++;
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
-                            best.t = __builtin_inff(); best.code = HIT_MISS; best.gid = 0xFFFFFFFFu;
+                            best.t = __builtin_inff(); best.code = HIT_MISS; best.aux = HIT_MISS;   // (no triangles: gid 0xFFFFFFFF, above every rank)
                             // (a ray that starts on a triangle does not hit it again -- k_shade has decided that -- and the
                             // traversal below skips it)
                             // (the pointer is laundered so that the reads stay here: hoisted out of the loop
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 if (src == (HIT_PLANE_BIT | p)) continue;   // t would be ~0 < 1e-5 in the reference's f64
                                 const float t = dot(mk(P0.x, P0.y, P0.z) - o, nrm) / dn;
                                 if (!(t >= 1e-5f)) continue;
-                                consider(best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w));
+                                consider(tris, tie_k, best, t, HIT_PLANE_BIT | p, __float_as_uint(P0.w));
                             }
                             // big spheres (kept out of the BVH), full f64
                             for (uint32_t pi = sc.n_leaf_prims; pi < sc.n_prims; ++pi) {
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 else { r0 = prims[3 * pi]; r1 = prims[3 * pi + 1]; r2 = prims[3 * pi + 2]; }
                                 if (COUNT) cnt_prims++;
                                 const float t = sphere_hit64(r0, r1, o, d, src == pi);
-                                if (t > 0.f) consider(best, t, pi, __float_as_uint(r2.y));
+                                if (t > 0.f) consider(tris, tie_k, best, t, pi, __float_as_uint(r2.y));
                             }
                             if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
@@ -538,7 +562,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 pcur = pend = 0;
                                 active = true;
                             } else {
-                                hits[ray] = make_float2(best.t, __uint_as_float(best.code));
+                                hits[ray] = make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code));
                             }
                         }
                     }
@@ -672,7 +696,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         const float ua = dot(tv, pv) * sg, ub = dot(d, qv) * sg, ut = dot(e2, qv) * sg, ad = fabsf(det);
                         if (ad > 0.f && ua >= 0.f && ub >= 0.f && ua + ub <= ad && ut >= 0.f) {
                             const float inv = 1.0f / ad;
-                            consider(best, ut * inv, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
+                            consider(tris, tie_k, best, ut * inv, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
                         }
                     }
                 } else {
@@ -681,7 +705,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     f3 o_ = o, d_ = d;
                     asm volatile("; RTMARK leaf_sphere" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
                     const float t = sphere_hit(L0, L1, o_, d_, src == pi);
-                    if (t > 0.f) consider(best, t, pi, gid);
+                    if (t > 0.f) consider(tris, tie_k, best, t, pi, gid);
                 }
                 asm volatile("; RTMARK leaf_end");
                 pcur++;
@@ -695,7 +719,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 asm volatile("; RTMARK control");
             }
             if (active && node == STACK_SENTINEL && pcur >= pend) {
-                hits[ray] = make_float2(best.t, __uint_as_float(best.code));
+                hits[ray] = make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code));
                 active = false;
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
@@ -792,9 +816,6 @@ __device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radianc
 #ifndef RT_SHADE_PREFETCH
 #define RT_SHADE_PREFETCH 1
 #endif
-#ifndef RT_SPHERE_REF64
-#define RT_SPHERE_REF64 1
-#endif
 #ifndef RT_SHADE_GRID_MUL
 #define RT_SHADE_GRID_MUL 2u
 #endif
@@ -848,6 +869,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         d3 p64 = mkd(0, 0, 0);
         uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
+        uint32_t near_tri = HIT_MISS;   // a triangle coplanar with the hit that lost the f64 comparison (see the tie resolution below)
         bool dir_exact = false;  // the scattered direction is the reference's f64 one: ndir holds its upper bits, d_lo the lower ones (RayQueue::f)
         uint32_t d_lo_x = 0, d_lo_y = 0, d_lo_z = 0;
         if (i < n) {
@@ -899,6 +921,52 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         d64 = dither64(d, dh);
                     }
                 };
+                d3 o64 = mkd(0, 0, 0);
+                if (TRIS) {
+                    ray64(o64);
+                    // Two candidates at the same distance as far as f32 can tell (k_closest_hit's runner-up: a box face in the
+                    // ground plane, a box on a box): the reference scans every object in f64 and keeps the smallest t, the
+                    // first in scan order on equality (scene.rs:35-50, intersections.rs:148-186), so which of two coplanar
+                    // surfaces a ray meets is decided by the roundings of two f64 distances, ray by ray.  Both distances
+                    // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
+                    // that leaves may meet it at t ~ 1e-16 (leaves_src).
+                    const uint32_t code2 = __float_as_uint(H.x);
+                    if (code2 != HIT_MISS && code2 != code) {
+                        auto ref_t = [&](uint32_t c) -> double {
+#pragma clang fp contract(off)
+                            const double none = __builtin_inf();
+                            if (c & HIT_PLANE_BIT) {                                           // intersections.rs:84-93
+                                const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)(c & ~HIT_PLANE_BIT);
+                                const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
+                                const double dot_nd = dot_ref(n64, d64);
+                                if (fabs(dot_nd) < 1e-6) return none;
+                                const double tp = dot_ref(sub_ref(c64, o64), n64) / dot_nd;
+                                return tp < 1e-5 ? none : tp;
+                            }
+                            const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)c;
+                            const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
+                            if (!(__float_as_uint(rec[0].w) & SMETA_SPHERE)) {                 // intersections.rs:153-168
+                                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                                double t0, a, b;
+                                return tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b) ? t0 : none;
+                            }
+                            const double2 c0 = r64[0], c1 = r64[1];                            // intersections.rs:42-67
+                            const d3 oc = sub_ref(o64, mkd(c0.x, c0.y, c1.x));
+                            const double qa = dot_ref(d64, d64), qb = 2.0 * dot_ref(d64, oc), qc = dot_ref(oc, oc) - c1.y * c1.y;
+                            double disc = qb * qb - 4.0 * qa * qc;
+                            if (!(disc >= 0.0)) return none;
+                            disc = sqrt(disc);
+                            const double t1 = (-qb - disc) / (2.0 * qa), t2 = (-qb + disc) / (2.0 * qa);
+                            return t1 > 1e-5 ? t1 : (t2 > 1e-5 ? t2 : none);
+                        };
+                        const double ta = ref_t(code), tb = ref_t(code2);
+                        const bool second = tb < ta || (tb == ta && gid_of(sc, code2) < gid_of(sc, code));
+                        const uint32_t lose = second ? code : code2;
+                        if (second) code = code2;
+                        // (a loser the f64 test rejects altogether is no neighbour)
+                        if (!(lose & HIT_PLANE_BIT) && (second ? ta : tb) < __builtin_inf() && !(__float_as_uint(sc.smeta[SMETA_WORDS * (size_t)lose].w) & SMETA_SPHERE)) near_tri = lose;
+                    }
+                }
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
                     const float4 P1 = sc.planes[2 * pl + 1];
@@ -911,8 +979,6 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
 #pragma clang fp contract(off)
                         const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)pl;
                         const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
-                        d3 o64;
-                        ray64(o64);
                         const double dot_nd = n64.x * d64.x + n64.y * d64.y + n64.z * d64.z;
                         const d3 co = sub_ref(c64, o64);
                         const double t64 = (co.x * n64.x + co.y * n64.y + co.z * n64.z) / dot_nd;
@@ -935,8 +1001,6 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
                         const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
-                        d3 o64;
-                        ray64(o64);
                         double t0, a, b;
                         tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                         p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
@@ -951,7 +1015,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         }
                     } else {
                         const float4 r0 = rec[1], r1 = rec[2];
-                        if (TRIS && RT_SPHERE_REF64) {
+                        if (TRIS) {
                             // intersections.rs:42-69 in f64, operation by operation: in scenes with triangles every hit point
                             // is the reference's own f64 function of the ray, because the rays that leave it carry it as
                             // their origin and the last bits of an origin decide what happens on the triangle it reaches
@@ -960,8 +1024,6 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                             const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
                             const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
                             const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
-                            d3 o64;
-                            ray64(o64);
                             const d3 oc = sub_ref(o64, mkd(cx, cy, cz));
                             const double qa = d64.x * d64.x + d64.y * d64.y + d64.z * d64.z;
                             const double qb = 2.0 * (d64.x * oc.x + d64.y * oc.y + d64.z * oc.z);
@@ -1100,17 +1162,32 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         // rng_out: the rng word the emitted ray carries.  The verdict is formed on the very f64 ray the next k_shade will form
         // from the queue words (same origin bits, same dither bits of the direction: the next launch derives them from
         // that word), as in the reference, where the verdict IS the next intersection.
-        // exact: dir_out is ndir after a specular bounce, whose f64 value travels with the ray (SRC_D_BIT)
+        // exact: dir_out is ndir after a specular bounce, whose f64 value travels with the ray (SRC_D_BIT).
+        // Besides the triangle the ray starts on there may be a coplanar neighbour (near_tri: the face of another box, or
+        // a box face in the plane that was hit): the reference meets whichever its f64 test accepts at the smaller t, the
+        // first in scan order on equality.  A ray that leaves a plane names the neighbour as the primitive to skip (the
+        // plane itself needs no name: t ~ 0 fails its t >= 1e-5).
         auto leaves_src = [&](f3 dir_out, bool exact, uint32_t rng_out, uint32_t& src_out) -> bool {
-            src_out = has_p64 ? (code | SRC_E_BIT | (exact ? SRC_D_BIT : 0u)) : code;
-            if (!TRIS || !on_tri) return false;
+            const uint32_t flags = has_p64 ? (SRC_E_BIT | (exact ? SRC_D_BIT : 0u)) : 0u;
+            src_out = code | flags;
+            if (!TRIS || (!on_tri && near_tri == HIT_MISS)) return false;
+            if (!on_tri) src_out = near_tri | flags;
             uint32_t dh = pcg_hash(rng_out ^ 0x68E31DA4u);
-            const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
-            const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
             const d3 nd64 = exact ? mkd(join64(dir_out.x, d_lo_x), join64(dir_out.y, d_lo_y), join64(dir_out.z, d_lo_z)) : dither64(dir_out, dh);
-            double t1, a1, b1;
-            if (!tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1)) return false;
-            src_out |= SRC_SELF_BIT;
+            auto test = [&](uint32_t c, double& t1) -> bool {
+                const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)c + 1);
+                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
+                double a1, b1;
+                return tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1);
+            };
+            uint32_t who = HIT_MISS;
+            double t_self = 0.0, t_near = 0.0;
+            if (on_tri && test(code, t_self)) who = code;
+            if (near_tri != HIT_MISS && test(near_tri, t_near)) {       // rare
+                if (who == HIT_MISS || t_near < t_self || (t_near == t_self && gid_of(sc, near_tri) < gid_of(sc, code))) who = near_tri;
+            }
+            if (who == HIT_MISS) return false;
+            src_out = who | SRC_SELF_BIT | flags;
             return true;
         };
         uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
@@ -1229,11 +1306,12 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     float tt = -1.f;
     f3 nrm = mk(0, 0, 0);
     if (code != HIT_MISS) {
-        tt = H.x;
+        tt = H.x;   // (scenes with triangles: the runner-up, see Best; the distance is formed again below)
         if (code & HIT_PLANE_BIT) {
             const uint32_t p = code & ~HIT_PLANE_BIT;
-            const float4 P1 = sc.planes[2 * p + 1];
+            const float4 P0 = sc.planes[2 * p], P1 = sc.planes[2 * p + 1];
             nrm = mk(P1.x, P1.y, P1.z);
+            if (sc.n_tris) tt = dot(mk(P0.x, P0.y, P0.z) - mk(A.x, A.y, A.z), nrm) / dot(nrm, mk(A.w, B.x, B.y));
             o = sc.plane_object[p];
         } else {
             const float4 r0 = sc.prims[3 * code], r1 = sc.prims[3 * code + 1], r2 = sc.prims[3 * code + 2];
@@ -1252,6 +1330,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
                             mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                 tt = (float)t0;
             } else {
+                if (sc.n_tris) tt = code >= sc.n_leaf_prims ? sphere_hit64(r0, r1, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), false) : sphere_hit(r0, r1, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), false);
                 nrm = sphere_normal(r0, r1, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), tt);
             }
         }
