@@ -96,6 +96,10 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
     return x < sc.width && row < sc.height;
 }
 
+#ifndef RT_PRIMARY_REF64
+#define RT_PRIMARY_REF64 1
+#endif
+__device__ __forceinline__ void split64(double v, float& hi, uint32_t& lo);
 __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
                                                 uint32_t* __restrict__ ctl, uint32_t capacity) {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -128,7 +132,14 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
             const double ddz = sc.lle[2] + sc.hz[2] * px + sc.vt[2] * py;
             const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
             const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
-            const f3 d = mk((float)(ddx * inv), (float)(ddy * inv), (float)(ddz * inv));
+            f3 d = mk((float)(ddx * inv), (float)(ddy * inv), (float)(ddz * inv));
+#if RT_PRIMARY_REF64
+            if (sc.n_tris) {   // the f64 direction travels exactly (see RayQueue::e): f32 truncation in a, the bits below in e
+                uint4 lo = make_uint4(0u, 0u, 0u, 0u);
+                split64(ddx * inv, d.x, lo.x); split64(ddy * inv, d.y, lo.y); split64(ddz * inv, d.z, lo.z);
+                q.e[pid] = lo;
+            }
+#endif
             A = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
         }
         q.a[pid] = A;
@@ -837,6 +848,46 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
     return slot;
 }
 
+// The reference's distance to primitive / plane `c` along the f64 ray, or +inf where it reports no hit
+// (intersections.rs:42-67, 84-93, 153-168), operation by operation.
+__device__ __forceinline__ double ref_t64(const DevScene& sc, uint32_t c, d3 o64, d3 d64) {
+#pragma clang fp contract(off)
+    const double none = __builtin_inf();
+    if (c & HIT_PLANE_BIT) {
+        const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)(c & ~HIT_PLANE_BIT);
+        const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
+        const double dot_nd = dot_ref(n64, d64);
+        if (fabs(dot_nd) < 1e-6) return none;
+        const double tp = dot_ref(sub_ref(c64, o64), n64) / dot_nd;
+        return tp < 1e-5 ? none : tp;
+    }
+    const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)c;
+    const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
+    if (!(__float_as_uint(rec[0].w) & SMETA_SPHERE)) {
+        const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+        double t0, a, b;
+        return tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b) ? t0 : none;
+    }
+    const double2 c0 = r64[0], c1 = r64[1];
+    const d3 oc = sub_ref(o64, mkd(c0.x, c0.y, c1.x));
+    const double qa = dot_ref(d64, d64), qb = 2.0 * dot_ref(d64, oc), qc = dot_ref(oc, oc) - c1.y * c1.y;
+    double disc = qb * qb - 4.0 * qa * qc;
+    if (!(disc >= 0.0)) return none;
+    disc = sqrt(disc);
+    const double t1 = (-qb - disc) / (2.0 * qa), t2 = (-qb + disc) / (2.0 * qa);
+    return t1 > 1e-5 ? t1 : (t2 > 1e-5 ? t2 : none);
+}
+// Hit and runner-up of k_closest_hit (two candidates at the same distance as far as f32 can tell): the one the reference
+// keeps -- the smaller f64 t, the first in scan order on equality (scene.rs:35-50, intersections.rs:148-186).  near_tri: the
+// loser, if it is a triangle the f64 test accepts (a coplanar neighbour the next ray may meet at t ~ 1e-16, see leaves_src).
+__device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t code, uint32_t code2, d3 o64, d3 d64, uint32_t& near_tri) {
+    const double ta = ref_t64(sc, code, o64, d64), tb = ref_t64(sc, code2, o64, d64);
+    const bool second = tb < ta || (tb == ta && gid_of(sc, code2) < gid_of(sc, code));
+    const uint32_t lose = second ? code : code2;
+    if (!(lose & HIT_PLANE_BIT) && (second ? ta : tb) < __builtin_inf() && !(__float_as_uint(sc.smeta[SMETA_WORDS * (size_t)lose].w) & SMETA_SPHERE)) near_tri = lose;
+    return second ? code2 : code;
+}
+
 // One thread per ray of iteration `it`.  last != 0: this is the last allowed bounce
 // (current_depth == max_depth-1) or a shadow-ray generation (trace(scene, 0, 1)): the
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
@@ -914,7 +965,10 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
                     else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                     else o64 = dither64(o, dh);
-                    if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
+                    if (RT_PRIMARY_REF64 && it == 0) {
+                        const uint4 E0 = qi.e[i];
+                        d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
+                    } else if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
                         const uint2 F = qi.f[i];
                         d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
                     } else {
@@ -931,41 +985,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
                     // that leaves may meet it at t ~ 1e-16 (leaves_src).
                     const uint32_t code2 = __float_as_uint(H.x);
-                    if (code2 != HIT_MISS && code2 != code) {
-                        auto ref_t = [&](uint32_t c) -> double {
-#pragma clang fp contract(off)
-                            const double none = __builtin_inf();
-                            if (c & HIT_PLANE_BIT) {                                           // intersections.rs:84-93
-                                const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)(c & ~HIT_PLANE_BIT);
-                                const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
-                                const double dot_nd = dot_ref(n64, d64);
-                                if (fabs(dot_nd) < 1e-6) return none;
-                                const double tp = dot_ref(sub_ref(c64, o64), n64) / dot_nd;
-                                return tp < 1e-5 ? none : tp;
-                            }
-                            const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)c;
-                            const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
-                            if (!(__float_as_uint(rec[0].w) & SMETA_SPHERE)) {                 // intersections.rs:153-168
-                                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
-                                double t0, a, b;
-                                return tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b) ? t0 : none;
-                            }
-                            const double2 c0 = r64[0], c1 = r64[1];                            // intersections.rs:42-67
-                            const d3 oc = sub_ref(o64, mkd(c0.x, c0.y, c1.x));
-                            const double qa = dot_ref(d64, d64), qb = 2.0 * dot_ref(d64, oc), qc = dot_ref(oc, oc) - c1.y * c1.y;
-                            double disc = qb * qb - 4.0 * qa * qc;
-                            if (!(disc >= 0.0)) return none;
-                            disc = sqrt(disc);
-                            const double t1 = (-qb - disc) / (2.0 * qa), t2 = (-qb + disc) / (2.0 * qa);
-                            return t1 > 1e-5 ? t1 : (t2 > 1e-5 ? t2 : none);
-                        };
-                        const double ta = ref_t(code), tb = ref_t(code2);
-                        const bool second = tb < ta || (tb == ta && gid_of(sc, code2) < gid_of(sc, code));
-                        const uint32_t lose = second ? code : code2;
-                        if (second) code = code2;
-                        // (a loser the f64 test rejects altogether is no neighbour)
-                        if (!(lose & HIT_PLANE_BIT) && (second ? ta : tb) < __builtin_inf() && !(__float_as_uint(sc.smeta[SMETA_WORDS * (size_t)lose].w) & SMETA_SPHERE)) near_tri = lose;
-                    }
+                    if (code2 != HIT_MISS && code2 != code) code = resolve_tie(sc, code, code2, o64, d64, near_tri);
                 }
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
@@ -1301,7 +1321,12 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     const size_t px = (size_t)row * sc.width + x;
     if (dout) { dout[px * 3 + 0] = D.x; dout[px * 3 + 1] = D.y; dout[px * 3 + 2] = D.z; }   // the ray k_raygen made (rt_primary_rays)
     if (!obj) return;
-    const uint32_t code = __float_as_uint(H.y);
+    uint32_t code = __float_as_uint(H.y);
+    if (sc.n_tris && code != HIT_MISS && __float_as_uint(H.x) != HIT_MISS && __float_as_uint(H.x) != code) {   // runner-up: as in k_shade
+        const d3 d64 = mkd((double)A.w, (double)B.x, (double)B.y);   // (the f32 ray rt_primary_rays reports, as for the triangle's t below)
+        uint32_t near_tri = HIT_MISS;
+        code = resolve_tie(sc, code, __float_as_uint(H.x), mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]), d64, near_tri);
+    }
     int32_t o = -1, t = -1;
     float tt = -1.f;
     f3 nrm = mk(0, 0, 0);
