@@ -97,17 +97,38 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 }
 
 #ifndef RT_PRIMARY_REF64
-#define RT_PRIMARY_REF64 1
+#define RT_PRIMARY_REF64 1   // scenes with triangles: k_shade forms the f64 direction of a primary ray again instead of widening its f32 copy
 #endif
-__device__ __forceinline__ void split64(double v, float& hi, uint32_t& lo);
+// The primary ray of path `pid` of a pass: sample position (anti_aliasing.rs:93-124), camera.rs:62-67 in f64 (lower_left +
+// horizontal*x + vertical*y - eye) and Ray::new's normalisation (raytrace.rs:32-37); raytrace.rs:128: output row 0 is
+// j = height-1.  false: a padding slot of a border tile.  rng: the path's generator after the two jitter draws.
+__device__ __forceinline__ bool primary_ray(const DevScene& sc, const PassParams& pp, uint32_t pid, uint32_t& rng, double& dx, double& dy, double& dz) {
+    const uint32_t s_local = pid / pp.npix_pad;
+    const uint32_t pl = pid - s_local * pp.npix_pad;
+    uint32_t x = 0, row = 0;
+    if (!slot_to_pixel(sc, pp, pl, x, row)) return false;
+    const uint32_t s = pp.s_begin + s_local;
+    const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
+    rng = pcg_hash(pcg_hash(pcg_hash((row * sc.width + x) ^ pp.seed_lo) + s) ^ pp.seed_hi);
+    float fx = (float)si * pp.step + pp.off_x, fy = (float)sj * pp.step + pp.off_y;
+    if (pp.jitter) {                                              // anti_aliasing.rs:117-120, gen_range(0.0..step)
+        fx += rng_unit(rng) * pp.step;
+        fy += rng_unit(rng) * pp.step;
+    }
+    const double px = (double)x + (double)fx, py = (double)(sc.height - 1u - row) + (double)fy;
+    const double ddx = sc.lle[0] + sc.hz[0] * px + sc.vt[0] * py;
+    const double ddy = sc.lle[1] + sc.hz[1] * px + sc.vt[1] * py;
+    const double ddz = sc.lle[2] + sc.hz[2] * px + sc.vt[2] * py;
+    const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+    const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
+    dx = ddx * inv; dy = ddy * inv; dz = ddz * inv;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
                                                 uint32_t* __restrict__ ctl, uint32_t capacity) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < pp.n_paths; pid += stride) {   // n_paths % 64 == 0: wave-uniform
-        const uint32_t s_local = pid / pp.npix_pad;
-        const uint32_t pl = pid - s_local * pp.npix_pad;
-        uint32_t x = 0, row = 0;
-        const bool valid = slot_to_pixel(sc, pp, pl, x, row);
         radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
         // slot == path id: no compaction (one atomic per wave on a single counter costs more than the
         // whole kernel).  Padding slots of border tiles are flagged and skipped downstream.
@@ -115,33 +136,9 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
         // its path id the slot and it starts on nothing; iteration 0 of k_closest_hit and k_shade fill
         // that in.  d == 0 marks a padding slot.  (48-byte primaries cost 2 ms more per 133 M paths.)
         float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-            const uint32_t s = pp.s_begin + s_local;
-            const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
-            uint32_t rng = pcg_hash(pcg_hash(pcg_hash((row * sc.width + x) ^ pp.seed_lo) + s) ^ pp.seed_hi);
-            float fx = (float)si * pp.step + pp.off_x, fy = (float)sj * pp.step + pp.off_y;
-            if (pp.jitter) {                                              // anti_aliasing.rs:117-120, gen_range(0.0..step)
-                fx += rng_unit(rng) * pp.step;
-                fy += rng_unit(rng) * pp.step;
-            }
-            // camera.rs:62-67 in f64: lower_left + horizontal*x + vertical*y - eye, then Ray::new's
-            // normalisation (raytrace.rs:32-37); raytrace.rs:128: output row 0 is j = height-1
-            const double px = (double)x + (double)fx, py = (double)(sc.height - 1u - row) + (double)fy;
-            const double ddx = sc.lle[0] + sc.hz[0] * px + sc.vt[0] * py;
-            const double ddy = sc.lle[1] + sc.hz[1] * px + sc.vt[1] * py;
-            const double ddz = sc.lle[2] + sc.hz[2] * px + sc.vt[2] * py;
-            const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-            const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
-            f3 d = mk((float)(ddx * inv), (float)(ddy * inv), (float)(ddz * inv));
-#if RT_PRIMARY_REF64
-            if (sc.n_tris) {   // the f64 direction travels exactly (see RayQueue::e): f32 truncation in a, the bits below in e
-                uint4 lo = make_uint4(0u, 0u, 0u, 0u);
-                split64(ddx * inv, d.x, lo.x); split64(ddy * inv, d.y, lo.y); split64(ddz * inv, d.z, lo.z);
-                q.e[pid] = lo;
-            }
-#endif
-            A = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-        }
+        uint32_t rng;
+        double dx, dy, dz;
+        if (primary_ray(sc, pp, pid, rng, dx, dy, dz)) A = make_float4((float)dx, (float)dy, (float)dz, __uint_as_float(rng));
         q.a[pid] = A;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
@@ -894,7 +891,7 @@ __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t cod
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
 template <bool TRIS>
-__global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
+__global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, PassParams pp, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
@@ -966,8 +963,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                     else o64 = dither64(o, dh);
                     if (RT_PRIMARY_REF64 && it == 0) {
-                        const uint4 E0 = qi.e[i];
-                        d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
+                        // the f64 direction k_raygen rounded to f32, formed again (in the reference it is a unit vector to
+                        // 1e-16, and at exactly representable coordinates what the ray does on the triangle it reaches
+                        // depends on that; 16 more bytes per primary ray written and read cost 2.3 % of a C5 step)
+                        uint32_t r_;
+                        (void)primary_ray(sc, pp, pid, r_, d64.x, d64.y, d64.z);
                     } else if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
                         const uint2 F = qi.f[i];
                         d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
@@ -1407,11 +1407,11 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
     if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
     else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
 }
-void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
+void launch_shade(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
-    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, pp, qi, hits, qo, radiance, ctl, it, last, capacity);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, pp, qi, hits, qo, radiance, ctl, it, last, capacity);
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
