@@ -249,7 +249,7 @@ struct FlatScene {
     std::vector<uchar4> texels;
     uint32_t n_prims = 0, n_leaf_prims = 0, n_nodes = 0, n_planes = 0, n_lights = 0, n_tris = 0;
     float bg[3], eye[3];
-    double eye64[3], lle[3], hz[3], vt[3];
+    double eye64[3], lle[3], hz[3], vt[3], ll[3];
     uint32_t width = 0, height = 0, stack_depth = 2, bvh_depth = 0;
     double bvh_build_ms = 0;
 };
@@ -481,6 +481,7 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
         f.eye[k] = (float)d->cam_eye[k];
         f.eye64[k] = d->cam_eye[k];
         f.lle[k] = d->cam_lower_left[k] - d->cam_eye[k];
+        f.ll[k] = d->cam_lower_left[k];
         f.hz[k] = d->cam_horizontal[k];
         f.vt[k] = d->cam_vertical[k];
     }
@@ -510,7 +511,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     sc.n_planes = f.n_planes;
     sc.n_tris = f.n_tris;
     sc.n_lights = f.n_lights;
-    for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.eye64[k] = f.eye64[k]; sc.lle[k] = f.lle[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
+    for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.eye64[k] = f.eye64[k]; sc.lle[k] = f.lle[k]; sc.ll[k] = f.ll[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
     sc.width = f.width; sc.height = f.height;
     sc.stack_depth = f.stack_depth;
     sc.spill_levels = sc.stack_depth > LDS_STACK ? sc.stack_depth - LDS_STACK : 0;
@@ -665,6 +666,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             pp.tiles_x = tiles_x; pp.tiles_y = tiles_y; pp.tile_index = p->tile_index; pp.tile_count = tcount;
             pp.s_begin = s0; pp.n_samples = ns; pp.ssaa_n = p->ssaa_n; pp.jitter = p->ssaa_mode == RT_SSAA_JITTER;
             pp.step = 1.0f / (float)p->ssaa_n;                         // anti_aliasing.rs:94
+            pp.step64 = 1.0 / (double)p->ssaa_n;
             pp.off_x = (float)p->sample_offset[0]; pp.off_y = (float)p->sample_offset[1];
             pp.seed_lo = (uint32_t)p->seed; pp.seed_hi = (uint32_t)(p->seed >> 32);
             if (pp_out) *pp_out = pp;

@@ -112,6 +112,7 @@ struct DevScene {
     // primary-ray directions are formed in f64 (the reference's type) and rounded once:
     // an f32 camera loses 1e-4 relative in t on grazing rays
     double lle[3], hz[3], vt[3];          // lle = lower_left - eye
+    double ll[3];                         // lower_left
     uint32_t width, height;
     uint32_t stack_depth;     // traversal-stack entries a lane can need (bvh.h max_stack)
     uint32_t* spill;          // global overflow of the LDS stacks: [wave][level - LDS_STACK][lane]
@@ -128,6 +129,7 @@ struct PassParams {
     uint32_t ssaa_n;
     int32_t jitter;
     float step;
+    double step64;            // 1 / ssaa_n in f64 (anti_aliasing.rs:94)
     float off_x, off_y;
     uint32_t seed_lo, seed_hi;
 };

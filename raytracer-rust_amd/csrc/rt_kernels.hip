@@ -96,6 +96,12 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
     return x < sc.width && row < sc.height;
 }
 
+#ifndef RT_PRIMARY_REFORDER
+#define RT_PRIMARY_REFORDER 1
+#endif
+#ifndef RT_TIE_SHADE
+#define RT_TIE_SHADE 1    // 0: k_shade ignores the runner-up (measurements only)
+#endif
 #ifndef RT_PRIMARY_REF64
 #define RT_PRIMARY_REF64 1   // scenes with triangles: k_shade forms the f64 direction of a primary ray again instead of widening its f32 copy
 #endif
@@ -110,6 +116,36 @@ __device__ __forceinline__ bool primary_ray(const DevScene& sc, const PassParams
     const uint32_t s = pp.s_begin + s_local;
     const uint32_t si = s / pp.ssaa_n, sj = s - si * pp.ssaa_n;   // x-major sample order, anti_aliasing.rs:96-100
     rng = pcg_hash(pcg_hash(pcg_hash((row * sc.width + x) ^ pp.seed_lo) + s) ^ pp.seed_hi);
+#if RT_PRIMARY_REFORDER
+    // the reference's own f64 sequence: base + i * step + gen_range(0.0..step) (anti_aliasing.rs:93-124, 53 random bits),
+    // ((lower_left + horizontal * x) + vertical * y) - eye (camera.rs:62-67), x / norm (vec3.rs:115-121)
+    {
+#pragma clang fp contract(off)
+    double fx = (double)si * pp.step64, fy = (double)sj * pp.step64;
+    const double bx = (double)x + (double)pp.off_x, by = (double)(sc.height - 1u - row) + (double)pp.off_y;
+    double px = bx + fx, py = by + fy;
+    if (pp.jitter) {
+        const uint32_t a0 = rng_next(rng), a1 = rng_next(rng), b0 = rng_next(rng), b1 = rng_next(rng);
+        px += ((double)(a0 >> 5) * 67108864.0 + (double)(a1 >> 6)) * 0x1p-53 * pp.step64;
+        py += ((double)(b0 >> 5) * 67108864.0 + (double)(b1 >> 6)) * 0x1p-53 * pp.step64;
+    }
+    const double ddx = ((sc.ll[0] + sc.hz[0] * px) + sc.vt[0] * py) - sc.eye64[0];
+    const double ddy = ((sc.ll[1] + sc.hz[1] * px) + sc.vt[1] * py) - sc.eye64[1];
+    const double ddz = ((sc.ll[2] + sc.hz[2] * px) + sc.vt[2] * py) - sc.eye64[2];
+    const double dl = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+    if (dl != 0.0) {
+        // x / norm for three x: one division, then q = x * r corrected by its own remainder -- the last step of the division
+        // algorithm itself, the correctly rounded quotient but for rare double-rounding cases (two divisions less per ray,
+        // here and in k_shade's copy: 0.2 ms of a C5 step)
+        const double r = 1.0 / dl;
+        double q;
+        q = ddx * r; dx = __builtin_fma(__builtin_fma(-q, dl, ddx), r, q);
+        q = ddy * r; dy = __builtin_fma(__builtin_fma(-q, dl, ddy), r, q);
+        q = ddz * r; dz = __builtin_fma(__builtin_fma(-q, dl, ddz), r, q);
+    } else { dx = ddx; dy = ddy; dz = ddz; }
+    }
+    return true;
+#else
     float fx = (float)si * pp.step + pp.off_x, fy = (float)sj * pp.step + pp.off_y;
     if (pp.jitter) {                                              // anti_aliasing.rs:117-120, gen_range(0.0..step)
         fx += rng_unit(rng) * pp.step;
@@ -123,6 +159,7 @@ __device__ __forceinline__ bool primary_ray(const DevScene& sc, const PassParams
     const double inv = dl != 0.0 ? 1.0 / dl : 1.0;
     dx = ddx * inv; dy = ddy * inv; dz = ddz * inv;
     return true;
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
@@ -966,8 +1003,20 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // the f64 direction k_raygen rounded to f32, formed again (in the reference it is a unit vector to
                         // 1e-16, and at exactly representable coordinates what the ray does on the triangle it reaches
                         // depends on that; 16 more bytes per primary ray written and read cost 2.3 % of a C5 step)
+#if RT_PRIMARY_REF64 == 2
+                        // experiment: the f32 direction of the queue, normalised again in f64 (unit to 1e-16, no pass parameters)
+                        {
+                            const double x = (double)d.x, y = (double)d.y, z = (double)d.z;
+                            const double l2 = x * x + y * y + z * z;
+                            double r = 1.5 - 0.5 * l2;                 // 1/sqrt(l2) for l2 = 1 + O(1e-7): Newton from 1
+                            r = r * (1.5 - 0.5 * l2 * r * r);
+                            r = r * (1.5 - 0.5 * l2 * r * r);
+                            d64 = mkd(x * r, y * r, z * r);
+                        }
+#else
                         uint32_t r_;
                         (void)primary_ray(sc, pp, pid, r_, d64.x, d64.y, d64.z);
+#endif
                     } else if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
                         const uint2 F = qi.f[i];
                         d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
@@ -985,7 +1034,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
                     // that leaves may meet it at t ~ 1e-16 (leaves_src).
                     const uint32_t code2 = __float_as_uint(H.x);
-                    if (code2 != HIT_MISS && code2 != code) code = resolve_tie(sc, code, code2, o64, d64, near_tri);
+                    if (RT_TIE_SHADE && code2 != HIT_MISS && code2 != code) code = resolve_tie(sc, code, code2, o64, d64, near_tri);
                 }
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;

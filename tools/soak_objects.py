@@ -76,6 +76,7 @@ def main():
     n_obj, findings, cleared, zs = 0, 0, 0, []
     for seed in range(int(sys.argv[1]), int(sys.argv[2]) + 1):
         objs, bg, cam, depth, rn = scene(seed)
+        depth = int(os.environ.get("SOAK_DEPTH", depth))
         try:
             ctx.upload(rt.Scene.from_objects(W, H, bg, cam, objs))
         except rt.RtError as e:
