@@ -143,7 +143,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].b, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].c, (size_t)capacity * sizeof(float4)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].e, (size_t)capacity * sizeof(uint4)));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].f, (size_t)capacity * sizeof(uint2)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].f, (size_t)capacity * sizeof(uint4)));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
@@ -573,7 +573,7 @@ static inline size_t align256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 // bytes of static scratch a pass of `paths` paths needs (rtamd.h: RT_NOALLOC_SCRATCH_BYTES)
 static size_t noalloc_bytes(uint32_t paths, uint32_t per_path) {
     const size_t cap = (size_t)paths * per_path;
-    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + 2 * align256(cap * sizeof(uint4)) + 2 * align256(cap * sizeof(uint2)) +
+    return align256(CTL_WORDS * sizeof(uint32_t)) + 6 * align256(cap * sizeof(float4)) + 4 * align256(cap * sizeof(uint4)) +
            align256(cap * sizeof(float2)) + align256((size_t)paths * sizeof(float4));
 }
 
@@ -621,7 +621,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             ws.q[k].b = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].c = reinterpret_cast<float4*>(carve(cap * sizeof(float4)));
             ws.q[k].e = reinterpret_cast<uint4*>(carve(cap * sizeof(uint4)));
-            ws.q[k].f = reinterpret_cast<uint2*>(carve(cap * sizeof(uint2)));
+            ws.q[k].f = reinterpret_cast<uint4*>(carve(cap * sizeof(uint4)));
         }
         ws.hits = reinterpret_cast<float2*>(carve(cap * sizeof(float2)));
         ws.radiance = reinterpret_cast<float4*>(carve((size_t)paths * sizeof(float4)));

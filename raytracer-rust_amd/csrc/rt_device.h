@@ -55,17 +55,19 @@ static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 //       an f32 rounding with random low bits gave 0.54 instead of 0.34 as the re-hit rate of a triangle behind a mirror
 //       plane at y = -0.6 (a point of that plane has y = -0.6 to an ulp of f64 in the reference), and +4 ... +11 % on
 //       axis-aligned boxes seen through a glass sphere
-//   f = with e.w: the same for the x (e.w), y, z (f) of the DIRECTION of a ray that left a mirror or a dielectric (SRC_D_BIT),
-//       which the reference computes from the arriving ray alone (materials.rs:119-183): its last bits are tied to that
-//       ray's (reflecting off an axis-aligned face flips one sign and changes nothing else), and that decides what the
-//       ray does on the next triangle.  Diffuse and fuzzy bounces add a random vector: their directions stay f32 and get
-//       random low bits where they enter f64 arithmetic
+//   f = (low bits of d.y, of d.z, neighbour, 0).  With e.w: the same for the x (e.w), y, z of the DIRECTION of a ray that left a
+//       mirror or a dielectric on a triangle or a plane (SRC_D_BIT), which the reference computes from the arriving ray alone
+//       (materials.rs:119-183): its last bits are tied to that ray's (reflecting off an axis-aligned face flips one sign and
+//       changes nothing else), and that decides what the ray does on the next triangle.  Diffuse and fuzzy bounces add a
+//       random vector: their directions stay f32 and get random low bits where they enter f64 arithmetic.  neighbour: for a
+//       ray that re-hits a triangle at t ~ 0 (SRC_SELF_BIT) the coplanar partner of that triangle, if there is one (two
+//       coincident faces; HIT_MISS otherwise).  Touched only by rays with SRC_D_BIT or SRC_SELF_BIT
 struct RayQueue {
     float4* a;
     float4* b;
     float4* c;
     uint4* e;
-    uint2* f;
+    uint4* f;
 };
 
 // Primitive record, 48 bytes = 3 x float4, stored in BVH leaf order.

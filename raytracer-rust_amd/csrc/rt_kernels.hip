@@ -741,7 +741,14 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         const float ua = dot(tv, pv) * sg, ub = dot(d, qv) * sg, ut = dot(e2, qv) * sg, ad = fabsf(det);
                         if (ad > 0.f && ua >= 0.f && ub >= 0.f && ua + ub <= ad && ut >= 0.f) {
                             const float inv = 1.0f / ad;
-                            consider(tris, tie_k, best, ut * inv, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
+                            const float t = ut * inv;
+                            // No triangle at t ~ 0: from a point ON a surface f32 cannot tell the reference's t = +1e-16 (a
+                            // hit, intersections.rs:166 has no epsilon) from -1e-16.  k_shade has decided those in f64 for the
+                            // triangle the ray starts on and for a coplanar neighbour (SRC_SELF_BIT); what is left here are
+                            // the neighbour of a ray that k_shade found to LEAVE both, and third faces in the same plane.
+                            // (A true hit this close -- within 1e-5 of an edge between two faces -- is lost with them.)
+                            if (t > 0x1p-17f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)))
+                                consider(tris, tie_k, best, t, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
                         }
                     }
                 } else {
@@ -1017,11 +1024,13 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         uint32_t r_;
                         (void)primary_ray(sc, pp, pid, r_, d64.x, d64.y, d64.z);
 #endif
-                    } else if (RT_DIR_REF64 && carried && (src & SRC_D_BIT)) {
-                        const uint2 F = qi.f[i];
-                        d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
                     } else {
-                        d64 = dither64(d, dh);
+                        const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
+                        uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
+                        if (exact_d || self_ray) F = qi.f[i];
+                        if (exact_d) d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
+                        else d64 = dither64(d, dh);
+                        if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
                     }
                 };
                 d3 o64 = mkd(0, 0, 0);
@@ -1236,7 +1245,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         // a box face in the plane that was hit): the reference meets whichever its f64 test accepts at the smaller t, the
         // first in scan order on equality.  A ray that leaves a plane names the neighbour as the primitive to skip (the
         // plane itself needs no name: t ~ 0 fails its t >= 1e-5).
-        auto leaves_src = [&](f3 dir_out, bool exact, uint32_t rng_out, uint32_t& src_out) -> bool {
+        auto leaves_src = [&](f3 dir_out, bool exact, uint32_t rng_out, uint32_t& src_out, uint32_t& other_out) -> bool {
+            other_out = HIT_MISS;
             const uint32_t flags = has_p64 ? (SRC_E_BIT | (exact ? SRC_D_BIT : 0u)) : 0u;
             src_out = code | flags;
             if (!TRIS || (!on_tri && near_tri == HIT_MISS)) return false;
@@ -1257,6 +1267,9 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             }
             if (who == HIT_MISS) return false;
             src_out = who | SRC_SELF_BIT | flags;
+            // the ray that leaves `who` may in turn meet the other one of the pair: it travels on as that ray's neighbour
+            // (queue word f), so that two coincident faces hand a path back and forth as they do in the reference
+            other_out = who == code ? near_tri : (on_tri ? code : HIT_MISS);
             return true;
         };
         uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
@@ -1264,8 +1277,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             split64(p64.x, p.x, p_lo.x); split64(p64.y, p.y, p_lo.y); split64(p64.z, p.z, p_lo.z);
         }
         dir_exact = dir_exact && has_p64 && emit;
-        uint32_t src_next = code;
-        if (!last && emit) (void)leaves_src(ndir, dir_exact, rng, src_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
+        uint32_t src_next = code, other_next = HIT_MISS;
+        if (!last && emit) (void)leaves_src(ndir, dir_exact, rng, src_next, other_next);   // before the claim: its loads and f64 work overlap nothing behind the barriers
         if (RT_SHADE_PREFETCH) {
             const uint64_t j = (uint64_t)i + stride;
             if (j < n) load_round((uint32_t)j);
@@ -1280,7 +1293,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
                     if (TRIS && has_p64) qo.e[slot] = make_uint4(p_lo.x, p_lo.y, p_lo.z, d_lo_x);
-                    if (TRIS && RT_DIR_REF64 && dir_exact) qo.f[slot] = make_uint2(d_lo_y, d_lo_z);
+                    if (TRIS && (dir_exact || (src_out >> 30) == 1u)) qo.f[slot] = make_uint4(d_lo_y, d_lo_z, other_next, 0u);
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -1294,13 +1307,14 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     if (slot >= capacity) { atomicAdd(&ctl[CTL_OVERFLOW], 1u); continue; }
                     const float4 Lp = sc.lights[l];
                     const f3 sd = normalized(mk(Lp.x, Lp.y, Lp.z) - p);      // raytrace.rs:79-82
-                    uint32_t src_out;
+                    uint32_t src_out, other_out;
                     const uint32_t rng_l = pcg_hash(rng + 0x9E3779B9u * (l + 1u));
-                    (void)leaves_src(sd, false, rng_l, src_out);
+                    (void)leaves_src(sd, false, rng_l, src_out, other_out);
                     qo.a[slot] = make_float4(p.x, p.y, p.z, sd.x);
                     qo.b[slot] = make_float4(sd.y, sd.z, __uint_as_float(src_out), __uint_as_float(pid));
                     qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng_l));
                     if (TRIS && has_p64) qo.e[slot] = p_lo;
+                    if (TRIS && (src_out >> 30) == 1u) qo.f[slot] = make_uint4(0u, 0u, other_out, 0u);
                 }
             }
         }
