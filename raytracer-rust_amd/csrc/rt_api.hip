@@ -706,7 +706,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                 // 0: a bounce before the last; 1: last bounce or a shadow generation, shadow rays go to the next
                 // generation; 2: the last generation this call runs (max_shadow_generations): nothing is emitted
                 const int last = it + 1 < depth ? 0 : (it + 1 < iters ? 1 : 2);
-                launch_shade(ctx->cfg, sc, pp, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, st);
+                launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, st);
             }
             if (!hits_only) launch_accumulate(sc, pp, ws.radiance, accum_dev, st);
             launch_stats(ws.ctl, ctx->stats_dev, capacity, st);

@@ -103,11 +103,12 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #define RT_TIE_SHADE 1    // 0: k_shade ignores the runner-up (measurements only)
 #endif
 #ifndef RT_PRIMARY_REF64
-#define RT_PRIMARY_REF64 1   // scenes with triangles: k_shade forms the f64 direction of a primary ray again instead of widening its f32 copy
+#define RT_PRIMARY_REF64 1   // scenes with triangles: the f64 direction of a primary ray travels exactly (queue word e)
 #endif
 // The primary ray of path `pid` of a pass: sample position (anti_aliasing.rs:93-124), camera.rs:62-67 in f64 (lower_left +
 // horizontal*x + vertical*y - eye) and Ray::new's normalisation (raytrace.rs:32-37); raytrace.rs:128: output row 0 is
 // j = height-1.  false: a padding slot of a border tile.  rng: the path's generator after the two jitter draws.
+__device__ __forceinline__ void split64(double v, float& hi, uint32_t& lo);
 __device__ __forceinline__ bool primary_ray(const DevScene& sc, const PassParams& pp, uint32_t pid, uint32_t& rng, double& dx, double& dy, double& dz) {
     const uint32_t s_local = pid / pp.npix_pad;
     const uint32_t pl = pid - s_local * pp.npix_pad;
@@ -175,7 +176,16 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
         float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t rng;
         double dx, dy, dz;
-        if (primary_ray(sc, pp, pid, rng, dx, dy, dz)) A = make_float4((float)dx, (float)dy, (float)dz, __uint_as_float(rng));
+        if (primary_ray(sc, pp, pid, rng, dx, dy, dz)) {
+            A = make_float4((float)dx, (float)dy, (float)dz, __uint_as_float(rng));
+            if (RT_PRIMARY_REF64 && sc.n_tris) {
+                // scenes with triangles: the f64 direction travels exactly, f32 truncation in a, the bits below in e (see
+                // RayQueue::e; forming it again in k_shade costs more than these 16 + 16 bytes: registers)
+                uint4 lo = make_uint4(0u, 0u, 0u, 0u);
+                split64(dx, A.x, lo.x); split64(dy, A.y, lo.y); split64(dz, A.z, lo.z);
+                q.e[pid] = lo;
+            }
+        }
         q.a[pid] = A;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
@@ -935,7 +945,7 @@ __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t cod
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
 template <bool TRIS>
-__global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, PassParams pp, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
+__global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
@@ -1007,23 +1017,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                     else o64 = dither64(o, dh);
                     if (RT_PRIMARY_REF64 && it == 0) {
-                        // the f64 direction k_raygen rounded to f32, formed again (in the reference it is a unit vector to
-                        // 1e-16, and at exactly representable coordinates what the ray does on the triangle it reaches
-                        // depends on that; 16 more bytes per primary ray written and read cost 2.3 % of a C5 step)
-#if RT_PRIMARY_REF64 == 2
-                        // experiment: the f32 direction of the queue, normalised again in f64 (unit to 1e-16, no pass parameters)
-                        {
-                            const double x = (double)d.x, y = (double)d.y, z = (double)d.z;
-                            const double l2 = x * x + y * y + z * z;
-                            double r = 1.5 - 0.5 * l2;                 // 1/sqrt(l2) for l2 = 1 + O(1e-7): Newton from 1
-                            r = r * (1.5 - 0.5 * l2 * r * r);
-                            r = r * (1.5 - 0.5 * l2 * r * r);
-                            d64 = mkd(x * r, y * r, z * r);
-                        }
-#else
-                        uint32_t r_;
-                        (void)primary_ray(sc, pp, pid, r_, d64.x, d64.y, d64.z);
-#endif
+                        // in the reference a primary direction is a unit vector to 1e-16 with the bits of its own f64
+                        // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
+                        // reaches depends on them
+                        const uint4 E0 = qi.e[i];
+                        d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
                     } else {
                         const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
                         uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
@@ -1470,11 +1468,11 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
     if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
     else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
 }
-void launch_shade(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
+void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
-    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, pp, qi, hits, qo, radiance, ctl, it, last, capacity);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, pp, qi, hits, qo, radiance, ctl, it, last, capacity);
+    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);

@@ -161,7 +161,9 @@ def main():
             # underestimate it when a few paths carry most of the light); the device's 4096 spp count as 16 such renders
             means = np.array([m.mean() for m in more])
             z = (D.mean() - means.mean()) / max(means.std(ddof=1) * np.sqrt(1.0 / 32.0 + 1.0 / 16.0), 1e-12)
-            flag = "" if (gain >= 0.0 and abs(z) <= 5.0) else "   <-- CONFIRMED at 2 x 4096 oracle spp"
+            # (expected gain here: the device's 4096 spp against the mean of 2 x 4096, 10 log10(2 / 1.5) = +1.25 dB, with a
+            # scatter of about 1 dB in rooms lit by a small mesh light; tools/room_noise.py compares the noise levels directly)
+            flag = "" if (gain >= -1.0 and abs(z) <= 5.0) else "   <-- CONFIRMED at 2 x 4096 oracle spp"
             if not flag:
                 flag = "   (flagged at 256 spp, cleared at 2 x 4096: gain %+.1f dB, z %+.2f)" % (gain, z)
                 cleared += 1
