@@ -165,8 +165,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, float*
  * RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, and the call
  * makes no hipMalloc / hipFree / event creation.  Limits, all reported as errors:
  *  - the call is ONE pass: paths = (tiles of the call) * 64 * (samples of the call) must satisfy
- *    13 KiB + paths * (16 + 144 * max(1, n_lights)) bytes <= RT_NOALLOC_SCRATCH_BYTES (about 419,000 paths
- *    without lights, 220,000 with two); split larger frames over several calls by sample range or tile set;
+ *    13 KiB + paths * (16 + 168 * max(1, n_lights)) bytes <= RT_NOALLOC_SCRATCH_BYTES (about 364,000 paths
+ *    without lights, 190,000 with two); split larger frames over several calls by sample range or tile set;
  *  - RT_FLAG_TIMING is refused (it creates events).
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two contexts, two streams)
  * race; calls in one stream are ordered.  Asynchronous on `stream` like rt_render_accumulate. */

@@ -59,7 +59,7 @@ def test_noalloc_limits_are_errors():
         sc = scenegen.scene_c3(width=640, height=360)
         ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
         acc = torch.zeros((ctx.height, ctx.width, 3), dtype=torch.float32, device="cuda:0")
-        # 640x360 = 230,400 paths per sample: one sample fits the 64 MiB scratch (160 B per path), two do not
+        # 640x360 = 230,400 paths per sample: one sample fits the 64 MiB scratch (184 B per path), two do not
         ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=1), acc)
         with pytest.raises(rt.RtError, match="static scratch"):
             ctx.render_accumulate_noalloc(rt.RenderParams("jitter:2", depth=3, sample_begin=0, sample_end=2), acc)
