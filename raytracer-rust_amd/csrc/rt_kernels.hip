@@ -456,7 +456,7 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 #define RT_HIT_MIN_WAVES 8   // waves per SIMD the register allocator must allow: 64 VGPRs, no spills (6 waves/80 VGPRs: 4.57 ms per launch, 7: 4.38, 8: 4.30)
 #endif
 
-template <bool COUNT>
+template <bool COUNT, bool TRIS>   // TRIS: the scene has triangles (what Best::aux holds, see consider)
 __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float2* __restrict__ hits, uint32_t* __restrict__ ctl,
                                                     int it, uint32_t capacity) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     float idx = 0.f, idy = 0.f, idz = 0.f;
     Best best;
-    const bool tris = sc.n_tris != 0u;                       // wave-uniform: what Best::aux holds, see consider
-    const float tie_k = tris ? 1.f + 2.f * RT_TIE_EPS : 1.f;
+    constexpr bool tris = TRIS;
+    constexpr float tie_k = TRIS ? 1.f + 2.f * RT_TIE_EPS : 1.f;
     best.t = 0.f; best.code = HIT_MISS; best.aux = HIT_MISS;
 
     for (;;) {
@@ -1031,17 +1031,20 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
                     }
                 };
-                d3 o64 = mkd(0, 0, 0);
                 if (TRIS) {
-                    ray64(o64);
                     // Two candidates at the same distance as far as f32 can tell (k_closest_hit's runner-up: a box face in the
                     // ground plane, a box on a box): the reference scans every object in f64 and keeps the smallest t, the
                     // first in scan order on equality (scene.rs:35-50, intersections.rs:148-186), so which of two coplanar
                     // surfaces a ray meets is decided by the roundings of two f64 distances, ray by ray.  Both distances
                     // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
-                    // that leaves may meet it at t ~ 1e-16 (leaves_src).
+                    // that leaves may meet it at t ~ 1e-16 (leaves_src).  (A rare branch of its own, ahead of the gathers of
+                    // the hit's records, so that they do not wait for the queue word of the f64 ray.)
                     const uint32_t code2 = __float_as_uint(H.x);
-                    if (RT_TIE_SHADE && code2 != HIT_MISS && code2 != code) code = resolve_tie(sc, code, code2, o64, d64, near_tri);
+                    if (RT_TIE_SHADE && code2 != HIT_MISS && code2 != code) {
+                        d3 o64t;
+                        ray64(o64t);
+                        code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
+                    }
                 }
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
@@ -1055,6 +1058,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
 #pragma clang fp contract(off)
                         const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)pl;
                         const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
+                        d3 o64;
+                        ray64(o64);
                         const double dot_nd = n64.x * d64.x + n64.y * d64.y + n64.z * d64.z;
                         const d3 co = sub_ref(c64, o64);
                         const double t64 = (co.x * n64.x + co.y * n64.y + co.z * n64.z) / dot_nd;
@@ -1077,6 +1082,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
                         const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                        d3 o64;
+                        ray64(o64);
                         double t0, a, b;
                         tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                         p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
@@ -1100,6 +1107,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                             const double cy = __hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
                             const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
                             const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+                            d3 o64;
+                            ray64(o64);
                             const d3 oc = sub_ref(o64, mkd(cx, cy, cz));
                             const double qa = d64.x * d64.x + d64.y * d64.y + d64.z * d64.z;
                             const double qb = 2.0 * (d64.x * oc.x + d64.y * oc.y + d64.z * oc.z);
@@ -1465,8 +1474,14 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
     if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
     const size_t lds = 0;
-    if (counters) hipLaunchKernelGGL(k_closest_hit<true>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
-    else hipLaunchKernelGGL(k_closest_hit<false>, dim3(blocks), dim3(256), lds, st, sc, q, hits, ctl, it, capacity);
+    const dim3 g(blocks), b(256);
+    if (sc.n_tris) {
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+    } else {
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+    }
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {

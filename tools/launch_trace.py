@@ -15,7 +15,7 @@ per_it = line["roofline"]["rays_per_iteration_per_step"]
 # the last TIMED step: bench.py's counters step (k_closest_hit<true>) comes after it and is left out
 gens = [i for i, r in enumerate(rows) if "k_raygen" in r["Kernel_Name"]] + [len(rows)]
 steps = [rows[a:b] for a, b in zip(gens[:-1], gens[1:])]
-step = [s for s in steps if any("k_closest_hit<false>" in r["Kernel_Name"] for r in s)][-1]
+step = [s for s in steps if any("k_closest_hit<false" in r["Kernel_Name"] for r in s)][-1]
 step = step[:max(i for i, r in enumerate(step) if "k_accumulate" in r["Kernel_Name"] or "k_shade" in r["Kernel_Name"]) + 1]
 hit = [r for r in step if "k_closest_hit" in r["Kernel_Name"]]
 shade = [r for r in step if "k_shade" in r["Kernel_Name"]]

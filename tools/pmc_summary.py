@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
             k = row["Kernel_Name"]
             for short in ("k_closest_hit", "k_shade", "k_raygen", "k_accumulate", "k_resolve", "k_stats"):
                 if short in k:
-                    k = short + ("<counters>" if short == "k_closest_hit" and "<true>" in k else "")
+                    k = short + ("<counters>" if short == "k_closest_hit" and "k_closest_hit<true" in k else "")
                     break
             else:
                 continue
