@@ -202,7 +202,7 @@ struct Best {
 
 // scene.rs:43 / intersections.rs:170: strict '>' while scanning in object/triangle order
 // == smallest t, then smallest scan rank (gid).
-// Scenes with triangles (tris, wave-uniform): two candidates whose f32 distances agree to RT_TIE_EPS are BOTH reported, the
+// Scenes with triangles (tris: k_closest_hit's template parameter): two candidates whose f32 distances agree to RT_TIE_EPS are BOTH reported, the
 // nearer as the hit, the other as the runner-up -- a box that stands exactly on the ground plane, a box on a box.  In the
 // reference the f64 roundings of the two distances decide which surface such a ray meets, ray by ray; the f32 order here
 // says nothing about that, so k_shade evaluates both with the reference's f64 sequences (see there).  The distances are
