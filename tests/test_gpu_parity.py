@@ -435,6 +435,22 @@ def test_boxes_at_exactly_representable_coordinates(ctx):
     assert abs(got / want - 1.0) < 0.008, (got, want)
 
 
+def test_two_boxes_with_coincident_faces(ctx):
+    """The front faces of two boxes lie in one plane (z = 0.25) and overlap; the second box is wound inwards.  In the reference
+    a ray that reaches them meets the one with the smaller f64 t (the first in scan order on equality), and the ray that leaves
+    re-hits whichever of the two accepts it at t ~ 1e-16 -- with the other material -- so a path is handed back and forth until
+    a hit point lands on the far side of the plane.  The device decides the arrival with the reference's two f64 distances, hands
+    the partner of a re-hit triangle on with the ray, and its f32 traversal takes no triangle at t ~ 0 (before: 0.32 of the
+    reference's radiance on the first box, tools/coincident_probe.py)."""
+    cam = dict(eye=[1.875, 1.875, 5.625], look_at=[0.375, 0.375, -0.375], up=[0.0, 1.0, 0.0], fovy=40.0)
+    a = dict(type="Mesh", verts=_box([-1.625, 0.5, -0.25], [-0.625, 1.375, 0.25]), tris=np.arange(36).reshape(12, 3), materials=[dict(type="Metal", albedo=[0.8, 0.7, 0.6], fuzziness=0.3)])
+    vb = _box([-1.875, 0.375, -1.25], [-0.75, 1.5, 0.25]).reshape(-1, 3, 3)[:, [0, 2, 1]].reshape(-1, 3)
+    b = dict(type="Mesh", verts=vb, tris=np.arange(36).reshape(12, 3), materials=[dict(type="Lambertian", albedo=[0.5, 0.6, 0.7])])
+    for obj in (0, 1):
+        got, want = _mean_where(ctx, [a, b], [0.7, 0.8, 0.9], cam, 48, 36, 4, lambda ids, img: ids == obj, 3 + obj, chan=slice(None))
+        assert abs(got / want - 1.0) < 0.03, (obj, got, want)
+
+
 # ------------------------------------------------------------------ properties
 def test_tile_split_union_is_bit_identical(ctx):
     load_pair("spheres", ctx)
