@@ -7,7 +7,7 @@ glass / diffuse ground planes, an optional glass or mirror sphere, an optional l
 Device: 4 renders of 4096 spp; oracle: 64 renders of 256 spp; standard errors from the spread of the oracle renders (a
 device render counts as 16 of them).  An object with |z| > 4 is looked at again with 256 oracle renders and 16 device
 renders; it is a finding if |z| > 4.5 stays and the means differ by more than 0.2 %.
-python tools/soak_objects.py <first seed> <last seed>"""
+python tools/soak_objects.py <first seed> <last seed>     (SOAK_TILT=1: every scene turned out of the axes as a whole; SOAK_DEPTH=n)"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -68,6 +68,19 @@ def scene(seed):
     else:
         cam = dict(eye=[coord(-2.0, 2.0), coord(0.3, 2.5), coord(5.0, 7.0)], look_at=[coord(-0.5, 0.5), coord(0.0, 0.6), coord(-1.0, 0.0)], up=[0.0, 1.0, 0.0], fovy=float(rng.uniform(30, 50)))
     bg = [float(x) for x in rng.uniform(0.3, 1.0, size=3)]
+    if os.environ.get("SOAK_TILT"):
+        # the same scene turned out of the axes as a whole: faces that coincided now coincide to a rounding error only, and no
+        # normal has an exact zero
+        a, b = rng.uniform(0.1, 0.6, size=2)
+        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        for o in objs:
+            if o["type"] == "Mesh":
+                o["verts"] = o["verts"] @ Rm.T
+            else:
+                o["center"] = [float(x) for x in Rm @ np.array(o["center"])]
+                if o["type"] == "Plane":
+                    o["normal"] = [float(x) for x in Rm @ np.array(o["normal"])]
+        cam = dict(cam, eye=[float(x) for x in Rm @ np.array(cam["eye"])], look_at=[float(x) for x in Rm @ np.array(cam["look_at"])], up=[float(x) for x in Rm @ np.array(cam["up"])])
     return objs, bg, cam, int(rng.integers(2, 9)), round_numbers
 
 
