@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 // direction after a specular bounce (SRC_D_BIT), a dithered f32 direction otherwise.
                 d3 d64 = mkd(0, 0, 0);
                 uint32_t sw = 0;
-                auto ray64 = [&](d3& o64) {
+                auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
                     dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
                     const bool carried = it != 0 && src < SRC_SPECIAL && (src & SRC_E_BIT);
                     uint4 E = make_uint4(0u, 0u, 0u, 0u);
@@ -1016,10 +1016,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
                     else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                     else o64 = dither64(o, dh);
-                    if (RT_PRIMARY_REF64 && it == 0) {
+                    if (RT_PRIMARY_REF64 && it == 0 && (flat || RT_PRIMARY_REF64 > 1)) {
                         // in the reference a primary direction is a unit vector to 1e-16 with the bits of its own f64
                         // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
-                        // reaches depends on them
+                        // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
+                        // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
                         const uint4 E0 = qi.e[i];
                         d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
                     } else {
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const uint32_t code2 = __float_as_uint(H.x);
                     if (RT_TIE_SHADE && code2 != HIT_MISS && code2 != code) {
                         d3 o64t;
-                        ray64(o64t);
+                        ray64(o64t, true);
                         code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
                     }
                 }
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         const double* __restrict__ P64 = sc.planes64 + 6 * (size_t)pl;
                         const d3 c64 = mkd(P64[0], P64[1], P64[2]), n64 = mkd(P64[3], P64[4], P64[5]);
                         d3 o64;
-                        ray64(o64);
+                        ray64(o64, true);
                         const double dot_nd = n64.x * d64.x + n64.y * d64.y + n64.z * d64.z;
                         const d3 co = sub_ref(c64, o64);
                         const double t64 = (co.x * n64.x + co.y * n64.y + co.z * n64.z) / dot_nd;
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
                         const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
                         d3 o64;
-                        ray64(o64);
+                        ray64(o64, true);
                         double t0, a, b;
                         tri_hit_ref(o64, d64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t0, a, b);
                         p64 = at_ref(o64, d64, t0);                                        // intersections.rs:172
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                             const double cz = __hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
                             const double rad = __hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
                             d3 o64;
-                            ray64(o64);
+                            ray64(o64, false);
                             const d3 oc = sub_ref(o64, mkd(cx, cy, cz));
                             const double qa = d64.x * d64.x + d64.y * d64.y + d64.z * d64.z;
                             const double qb = 2.0 * (d64.x * oc.x + d64.y * oc.y + d64.z * oc.z);
