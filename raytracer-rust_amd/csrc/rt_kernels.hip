@@ -412,19 +412,35 @@ __device__ __forceinline__ d3 dither64(f3 v, uint32_t& h) {
 }
 
 // An f64 coordinate as (f32 with the same sign, exponent and upper 23 mantissa bits, the 29 mantissa bits below): the form in
-// which a ray's f64 origin travels in the queue (RayQueue::e).  Outside the range of normal f32 numbers (|v| < 2^-126: a
-// coordinate that is exactly 0, mostly) the f32 rounding stands alone, marked by lo = ~0.
+// which a ray's f64 origin travels in the queue (RayQueue::e).  Below the range of normal f32 numbers (|v| < 2^-126) the pair
+// holds the f64 itself, less its 8 lowest mantissa bits, behind an f32 exponent field of 0: (sign | payload bits 54..32,
+// payload bits 31..0), payload = f64 exponent << 44 | mantissa >> 8 -- to an f32 reader a denormal, i.e. 0.  Such values
+// matter: a face in the plane y = 0 is left at y = 1e-15, re-hit at t = 3e-31, again at 7e-47, and the SIGN of that y
+// decides when the path gets out (intersections.rs:166 has no epsilon); with these flushed to 0 a glass box whose top face
+// lay in y = 0 kept 0.4 % of its paths for ever (tools/soak_objects.py seed 2444).  Above the f32 range: the f32 rounding.
 __device__ __forceinline__ void split64(double v, float& hi, uint32_t& lo) {
     const uint32_t hw = (uint32_t)__double2hiint(v), lw = (uint32_t)__double2loint(v);
     const uint32_t e = (hw >> 20) & 0x7FFu;
-    if (e <= 896u || e >= 1151u) { hi = (float)v; lo = 0xFFFFFFFFu; return; }
+    if (e >= 1151u) { hi = (float)v; lo = 0u; return; }          // (inf, NaN, |v| >= 2^128: f32 exponent field 255)
+    if (e <= 896u) {
+        // payload bits: 54..44 = e, 43..24 = hw mantissa (20 bits), 23..0 = lw >> 8
+        hi = __uint_as_float((hw & 0x80000000u) | (e << 12) | ((hw & 0xFFFFFu) >> 8));
+        lo = ((hw & 0xFFu) << 24) | (lw >> 8);
+        return;
+    }
     hi = __uint_as_float((hw & 0x80000000u) | ((e - 896u) << 23) | ((hw & 0xFFFFFu) << 3) | (lw >> 29));
     lo = lw & 0x1FFFFFFFu;
 }
 __device__ __forceinline__ double join64(float hi, uint32_t lo) {
-    if (lo == 0xFFFFFFFFu) return (double)hi;
     const uint32_t fb = __float_as_uint(hi);
-    const uint32_t hw = (fb & 0x80000000u) | ((((fb >> 23) & 0xFFu) + 896u) << 20) | ((fb >> 3) & 0xFFFFFu);
+    const uint32_t fe = (fb >> 23) & 0xFFu;
+    if (fe == 255u) return (double)hi;
+    if (fe == 0u) {
+        const uint32_t e = (fb >> 12) & 0x7FFu;
+        const uint32_t hw = (fb & 0x80000000u) | (e << 20) | ((fb & 0xFFFu) << 8) | (lo >> 24);
+        return __hiloint2double((int)hw, (int)(lo << 8));
+    }
+    const uint32_t hw = (fb & 0x80000000u) | ((fe + 896u) << 20) | ((fb >> 3) & 0xFFFFFu);
     return __hiloint2double((int)hw, (int)((fb << 29) | lo));
 }
 
