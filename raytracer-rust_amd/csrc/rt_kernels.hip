@@ -221,8 +221,10 @@ __device__ __forceinline__ void consider(bool tris, float tie_k, Best& best, flo
     if (tris) {
         const bool win = gap < 0.f;
         const uint32_t other = win ? best.code : code;
-        if (fabsf(gap) <= RT_TIE_EPS * t) best.aux = other;
-        else if (win) best.aux = HIT_MISS;
+        uint32_t aux = best.aux;
+        if (fabsf(gap) <= RT_TIE_EPS * t) aux = other;
+        else if (win) aux = HIT_MISS;
+        if ((best.aux >> 30) != 1u) best.aux = aux;                // (a candidate at t ~ 0 keeps the slot: AUX_NEAR_BIT, see the leaf step)
         if (win) { best.t = t; best.code = code; }
     } else if (gap < 0.f || (gap == 0.f && gid < best.aux)) {
         best.t = t; best.code = code; best.aux = gid;
@@ -768,13 +770,20 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         if (ad > 0.f && ua >= 0.f && ub >= 0.f && ua + ub <= ad && ut >= 0.f) {
                             const float inv = 1.0f / ad;
                             const float t = ut * inv;
-                            // No triangle at t ~ 0: from a point ON a surface f32 cannot tell the reference's t = +1e-16 (a
+                            // A triangle at t ~ 0: from a point ON a surface f32 cannot tell the reference's t = +1e-16 (a
                             // hit, intersections.rs:166 has no epsilon) from -1e-16.  k_shade has decided those in f64 for the
                             // triangle the ray starts on and for a coplanar neighbour (SRC_SELF_BIT); what is left here are
-                            // the neighbour of a ray that k_shade found to LEAVE both, and third faces in the same plane.
-                            // (A true hit this close -- within 1e-5 of an edge between two faces -- is lost with them.)
+                            // the neighbour of a ray that k_shade found to LEAVE both, third faces in the same plane -- and
+                            // true hits this close: the adjacent face at a concave crease, a mesh touching the surface the
+                            // ray starts on.  The bound grows with the coordinates (0.02 at 1000), so such a candidate is not
+                            // dropped (round 2 did: paths leaked through creases of meshes far from the origin) but handed
+                            // to k_shade beside the nearest hit beyond the bound, in the runner-up word with AUX_NEAR_BIT;
+                            // k_shade evaluates both with the reference's f64 sequence and keeps what the reference keeps
+                            // (resolve_tie).  One slot: of several such candidates the last one tested stays.
                             if (t > 0x1p-17f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)))
                                 consider(tris, tie_k, best, t, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
+                            else if (tris)
+                                best.aux = pi | AUX_NEAR_BIT;              // f32 cannot rank it: k_shade's f64 test decides (resolve_tie)
                         }
                     }
                 } else {
@@ -947,11 +956,16 @@ __device__ __forceinline__ double ref_t64(const DevScene& sc, uint32_t c, d3 o64
 // Hit and runner-up of k_closest_hit (two candidates at the same distance as far as f32 can tell): the one the reference
 // keeps -- the smaller f64 t, the first in scan order on equality (scene.rs:35-50, intersections.rs:148-186).  near_tri: the
 // loser, if it is a triangle the f64 test accepts (a coplanar neighbour the next ray may meet at t ~ 1e-16, see leaves_src).
-__device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t code, uint32_t code2, d3 o64, d3 d64, uint32_t& near_tri) {
-    const double ta = ref_t64(sc, code, o64, d64), tb = ref_t64(sc, code2, o64, d64);
-    const bool second = tb < ta || (tb == ta && gid_of(sc, code2) < gid_of(sc, code));
+__device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t code, uint32_t aux, d3 o64, d3 d64, uint32_t& near_tri) {
+    // aux: the runner-up (a hit code), or AUX_NEAR_BIT | triangle: a candidate at t ~ 0 that the f32 traversal could not rank
+    // (k_closest_hit's leaf step); code may then be HIT_MISS.  A candidate the f64 test rejects never wins.
+    const uint32_t code2 = (aux >> 30) == 1u ? (aux & SRC_PRIM_MASK) : aux;
+    const double none = __builtin_inf();
+    const double ta = code == HIT_MISS ? none : ref_t64(sc, code, o64, d64), tb = ref_t64(sc, code2, o64, d64);
+    if (code == HIT_MISS) return tb < none ? code2 : HIT_MISS;
+    const bool second = tb < ta || (tb == ta && tb < none && gid_of(sc, code2) < gid_of(sc, code));
     const uint32_t lose = second ? code : code2;
-    if (!(lose & HIT_PLANE_BIT) && (second ? ta : tb) < __builtin_inf() && !(__float_as_uint(sc.smeta[SMETA_WORDS * (size_t)lose].w) & SMETA_SPHERE)) near_tri = lose;
+    if (!(lose & HIT_PLANE_BIT) && (second ? ta : tb) < none && !(__float_as_uint(sc.smeta[SMETA_WORDS * (size_t)lose].w) & SMETA_SPHERE)) near_tri = lose;
     return second ? code2 : code;
 }
 
@@ -1010,6 +1024,52 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 rng = __float_as_uint(C.w);
             }
             code = __float_as_uint(H.y);
+            float u = 0.f, v = 0.f;
+            // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
+            // that left a triangle, a plane or a sphere (SRC_E_BIT), a dithered f32 origin otherwise; the carried f64
+            // direction after a specular bounce (SRC_D_BIT), a dithered f32 direction otherwise.
+            d3 d64 = mkd(0, 0, 0);
+            uint32_t sw = 0;
+            auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
+                dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
+                const bool carried = it != 0 && src < SRC_SPECIAL && (src & SRC_E_BIT);
+                uint4 E = make_uint4(0u, 0u, 0u, 0u);
+                if (carried) E = qi.e[i];
+                if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
+                else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
+                else o64 = dither64(o, dh);
+                if (RT_PRIMARY_REF64 && it == 0 && (flat || RT_PRIMARY_REF64 > 1)) {
+                    // in the reference a primary direction is a unit vector to 1e-16 with the bits of its own f64
+                    // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
+                    // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
+                    // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
+                    const uint4 E0 = qi.e[i];
+                    d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
+                } else {
+                    const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
+                    uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
+                    if (exact_d || self_ray) F = qi.f[i];
+                    if (exact_d) d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
+                    else d64 = dither64(d, dh);
+                    if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
+                }
+            };
+            if (TRIS) {
+                // Two candidates at the same distance as far as f32 can tell (k_closest_hit's runner-up: a box face in the
+                // ground plane, a box on a box): the reference scans every object in f64 and keeps the smallest t, the
+                // first in scan order on equality (scene.rs:35-50, intersections.rs:148-186), so which of two coplanar
+                // surfaces a ray meets is decided by the roundings of two f64 distances, ray by ray.  Both distances
+                // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
+                // that leaves may meet it at t ~ 1e-16 (leaves_src).  (A rare branch of its own, ahead of the gathers of
+                // the hit's records, so that they do not wait for the queue word of the f64 ray.)
+                // The same for a candidate at t ~ 0 (AUX_NEAR_BIT): the hit may then have been a miss so far.
+                const uint32_t code2 = __float_as_uint(H.x);
+                if (RT_TIE_SHADE && code != HIT_INVALID && code2 != HIT_MISS && code2 != code) {
+                    d3 o64t;
+                    ray64(o64t, true);
+                    code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
+                }
+            }
             if (code == HIT_INVALID) {
                 // padding slot: not a ray
             } else if (code == HIT_MISS) {
@@ -1018,51 +1078,6 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 float t = H.x;
                 f3 nrm;
                 int mat;
-                float u = 0.f, v = 0.f;
-                // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
-                // that left a triangle, a plane or a sphere (SRC_E_BIT), a dithered f32 origin otherwise; the carried f64
-                // direction after a specular bounce (SRC_D_BIT), a dithered f32 direction otherwise.
-                d3 d64 = mkd(0, 0, 0);
-                uint32_t sw = 0;
-                auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
-                    dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
-                    const bool carried = it != 0 && src < SRC_SPECIAL && (src & SRC_E_BIT);
-                    uint4 E = make_uint4(0u, 0u, 0u, 0u);
-                    if (carried) E = qi.e[i];
-                    if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
-                    else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
-                    else o64 = dither64(o, dh);
-                    if (RT_PRIMARY_REF64 && it == 0 && (flat || RT_PRIMARY_REF64 > 1)) {
-                        // in the reference a primary direction is a unit vector to 1e-16 with the bits of its own f64
-                        // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
-                        // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
-                        // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
-                        const uint4 E0 = qi.e[i];
-                        d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
-                    } else {
-                        const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
-                        uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
-                        if (exact_d || self_ray) F = qi.f[i];
-                        if (exact_d) d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
-                        else d64 = dither64(d, dh);
-                        if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
-                    }
-                };
-                if (TRIS) {
-                    // Two candidates at the same distance as far as f32 can tell (k_closest_hit's runner-up: a box face in the
-                    // ground plane, a box on a box): the reference scans every object in f64 and keeps the smallest t, the
-                    // first in scan order on equality (scene.rs:35-50, intersections.rs:148-186), so which of two coplanar
-                    // surfaces a ray meets is decided by the roundings of two f64 distances, ray by ray.  Both distances
-                    // are formed here with the reference's sequences; the loser is remembered: if it is a triangle, the ray
-                    // that leaves may meet it at t ~ 1e-16 (leaves_src).  (A rare branch of its own, ahead of the gathers of
-                    // the hit's records, so that they do not wait for the queue word of the f64 ray.)
-                    const uint32_t code2 = __float_as_uint(H.x);
-                    if (RT_TIE_SHADE && code2 != HIT_MISS && code2 != code) {
-                        d3 o64t;
-                        ray64(o64t, true);
-                        code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
-                    }
-                }
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
                     const float4 P1 = sc.planes[2 * pl + 1];
@@ -1409,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     if (dout) { dout[px * 3 + 0] = D.x; dout[px * 3 + 1] = D.y; dout[px * 3 + 2] = D.z; }   // the ray k_raygen made (rt_primary_rays)
     if (!obj) return;
     uint32_t code = __float_as_uint(H.y);
-    if (sc.n_tris && code != HIT_MISS && __float_as_uint(H.x) != HIT_MISS && __float_as_uint(H.x) != code) {   // runner-up: as in k_shade
+    if (sc.n_tris && __float_as_uint(H.x) != HIT_MISS && __float_as_uint(H.x) != code) {   // runner-up or candidate at t ~ 0: as in k_shade
         const d3 d64 = mkd((double)A.w, (double)B.x, (double)B.y);   // (the f32 ray rt_primary_rays reports, as for the triangle's t below)
         uint32_t near_tri = HIT_MISS;
         code = resolve_tie(sc, code, __float_as_uint(H.x), mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]), d64, near_tri);

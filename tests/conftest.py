@@ -16,3 +16,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Keeps what the parity tests MEASURED (not only that they passed): gpurun_out/parity_record.json."""
+    try:
+        from util import PARITY
+        if not PARITY:
+            return
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_record.json"), "w") as f:
+            json.dump({"exitstatus": int(exitstatus), "measured": PARITY}, f, indent=1, sort_keys=True, default=float)
+    except Exception as e:      # a read-only tree must not fail the suite
+        print("parity record not written: %s" % e)

@@ -15,3 +15,8 @@ def pkg():
 
 def sub(name):
     return importlib.import_module("raytracer-rust_amd." + name)
+
+
+# Measured parity figures (PSNR, bias, id mismatches, device / oracle ratios) that the GPU tests put here; conftest.py writes
+# them to gpurun_out/parity_record.json when the session ends, and a copy of a full run is kept under profiles/.
+PARITY = {}
