@@ -14,6 +14,8 @@ constexpr uint32_t HIT_INVALID = 0xFFFFFFFCu; // hit code of such a slot
 constexpr uint32_t SRC_SELF_BIT = 0x40000000u;  // src = SRC_SELF_BIT | triangle: the ray re-hits the triangle it starts on at t ~ 0 (decided by k_shade, see there)
 constexpr uint32_t SRC_E_BIT = 0x20000000u;     // src | SRC_E_BIT (src below SRC_SPECIAL): queue word e holds the ray's f64 origin (it leaves a triangle or a plane)
 constexpr uint32_t SRC_D_BIT = 0x10000000u;     // ... and e.w, f hold its f64 direction (it left a mirror or a dielectric); only with SRC_E_BIT
+constexpr uint32_t HIT_SPHERE_BIT = 0x20000000u; // hit code (scenes with triangles): the primitive is a sphere -- k_shade sorts the rays of a block by what they hit
+                                                 // (triangle / sphere / plane / nothing) before it shades them, see there; strip_hit() removes it
 constexpr uint32_t AUX_NEAR_BIT = 0x40000000u;  // runner-up word of a hit record (scenes with triangles): AUX_NEAR_BIT | triangle = a candidate at t ~ 0
                                                 // that the f32 traversal cannot rank against the nearest hit; k_shade's f64 test decides (resolve_tie)
 constexpr uint32_t SRC_SPECIAL = 0xFFFFFFF0u;   // SRC_NONE, SRC_INVALID: no flag bits to read
@@ -136,6 +138,7 @@ struct PassParams {
     double step64;            // 1 / ssaa_n in f64 (anti_aliasing.rs:94)
     float off_x, off_y;
     uint32_t seed_lo, seed_hi;
+    uint32_t clear_radiance;  // k_raygen zeroes the paths' radiance words: scenes with lights (shadow rays add to them), passes that shade nothing
 };
 
 }  // namespace rtamd

@@ -96,6 +96,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
     return x < sc.width && row < sc.height;
 }
 
+#ifndef RT_SHADE_SORT
+#define RT_SHADE_SORT 0   // 1: the rays of a block round are sorted by hit class through LDS (measured: C5 +1.5 %, C4 +2.5 % step time; see k_shade)
+#endif
 #ifndef RT_PRIMARY_REFORDER
 #define RT_PRIMARY_REFORDER 1
 #endif
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
                                                 uint32_t* __restrict__ ctl, uint32_t capacity) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < pp.n_paths; pid += stride) {   // n_paths % 64 == 0: wave-uniform
-        radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pp.clear_radiance) radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);   // (scenes without lights: every path stores its radiance exactly once, k_shade)
         // slot == path id: no compaction (one atomic per wave on a single counter costs more than the
         // whole kernel).  Padding slots of border tiles are flagged and skipped downstream.
         // A primary ray is 16 bytes, (d.x, d.y, d.z, bits(rng)): its origin is the eye, its throughput 1,
@@ -212,6 +215,10 @@ struct Best {
 #ifndef RT_TIE_EPS
 #define RT_TIE_EPS 0x1p-13f
 #endif
+// hit code without its class bit (HIT_SPHERE_BIT): the plain primitive index / plane code / HIT_MISS / HIT_INVALID
+__device__ __forceinline__ uint32_t strip_hit(uint32_t code) {
+    return (code >= SRC_SPECIAL || (code & HIT_PLANE_BIT)) ? code : (code & SRC_PRIM_MASK);
+}
 __device__ __forceinline__ uint32_t gid_of(const DevScene& sc, uint32_t code) {
     return __float_as_uint((code & HIT_PLANE_BIT) ? sc.planes[2 * (size_t)(code & ~HIT_PLANE_BIT)].w : sc.prims[3 * (size_t)code + 2].y);
 }
@@ -339,6 +346,13 @@ __device__ __forceinline__ f3 sphere_normal(const float4 r0, const float4 r1, f3
 // shift the probabilities (0.13 instead of 0.36 on one test triangle), while random low bits are what the reference's
 // own f64 directions carry.  (The same sequence in f32 -- round 1 -- gave
 // 0.05 ... 0.95 where the reference has 0.3; it only happened to agree on scenes/cube, whose coordinates are exact.)
+#ifndef RT_FAST_DIV
+#define RT_FAST_DIV 1
+#endif
+__device__ __forceinline__ double quot_ref(double x, double m, double r) {   // x / m, r = 1 / m (correctly rounded)
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-q, m, x), r, q);
+}
 struct d3 {
     double x, y, z;
 };
@@ -373,7 +387,11 @@ __device__ __forceinline__ d3 cross_ref(d3 a, d3 b) {            // vec3.rs:104-
 __device__ __forceinline__ d3 normalized_ref(d3 v) {             // vec3.rs:115-121
 #pragma clang fp contract(off)
     const double n = sqrt(dot_ref(v, v));
+#if RT_FAST_DIV
+    if (n != 0.0) { const double r = 1.0 / n; return mkd(quot_ref(v.x, n, r), quot_ref(v.y, n, r), quot_ref(v.z, n, r)); }
+#else
     if (n != 0.0) return mkd(v.x / n, v.y / n, v.z / n);
+#endif
     return v;
 }
 __device__ __forceinline__ d3 reflect_ref(d3 v, d3 n) {          // vec3.rs:129-131
@@ -395,9 +413,20 @@ __device__ __forceinline__ bool tri_hit_ref(d3 o, d3 d, d3 A, d3 ab, d3 ac, doub
 #pragma clang fp contract(off)
     const d3 res = sub_ref(o, A);
     const double m = det3_ref(d, ab, ac), mt = det3_ref(res, ab, ac), ma = det3_ref(d, res, ac), mb = det3_ref(d, ab, res);
+#if RT_FAST_DIV
+    // three quotients by one divisor: one division, then x / m = q + (x - q m) r with q = x r, r = 1 / m -- the last step of the
+    // division algorithm itself (Markstein), the correctly rounded quotient but for divisors whose mantissa is all ones.  M == 0
+    // (a ray in the triangle's plane): r = inf and every quotient is NaN where the reference has +-inf or NaN; both fail the
+    // comparisons below
+    const double r = 1.0 / m;
+    a = quot_ref(ma, m, r);
+    b = quot_ref(mb, m, r);
+    t = -quot_ref(mt, m, r);
+#else
     a = ma / m;
     b = mb / m;
     t = -(mt / m);
+#endif
     return a >= 0.0 && b >= 0.0 && a + b <= 1.0 && t >= 0.0;
 }
 // f32 value -> f64 with random bits in the 28 low mantissa bits the f32 does not have (|change| < half an f32 ulp)
@@ -620,7 +649,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 else { r0 = prims[3 * pi]; r1 = prims[3 * pi + 1]; r2 = prims[3 * pi + 2]; }
                                 if (COUNT) cnt_prims++;
                                 const float t = sphere_hit64(r0, r1, o, d, src == pi);
-                                if (t > 0.f) consider(tris, tie_k, best, t, pi, __float_as_uint(r2.y));
+                                if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
                             }
                             if (sc.n_leaf_prims) {
                                 const float ooeps = 0x1p-80f;
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     f3 o_ = o, d_ = d;
                     asm volatile("; RTMARK leaf_sphere" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
                     const float t = sphere_hit(L0, L1, o_, d_, src == pi);
-                    if (t > 0.f) consider(tris, tie_k, best, t, pi, gid);
+                    if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, gid);
                 }
                 asm volatile("; RTMARK leaf_end");
                 pcur++;
@@ -876,19 +905,6 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
     return r0 + (1.f - r0) * (x * x * x * x * x);
 }
 
-__device__ __forceinline__ void add_radiance(const DevScene& sc, float4* radiance, uint32_t pid, f3 c) {
-    if (sc.n_lights == 0) {
-        // without lights a path contributes exactly once (when it ends): plain 16-byte store
-        radiance[pid] = make_float4(c.x, c.y, c.z, 0.f);
-    } else {
-        // shadow rays of one path end in different lanes / launches
-        float* r = reinterpret_cast<float*>(radiance + pid);
-        atomicAdd(r + 0, c.x);
-        atomicAdd(r + 1, c.y);
-        atomicAdd(r + 2, c.z);
-    }
-}
-
 // Block-level compaction: every thread of the block must call this (converged).  Threads with
 // `want` get `per_lane` consecutive slots; ONE atomic per 1024-thread block.
 #ifndef RT_SHADE_THREADS
@@ -959,7 +975,7 @@ __device__ __forceinline__ double ref_t64(const DevScene& sc, uint32_t c, d3 o64
 __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t code, uint32_t aux, d3 o64, d3 d64, uint32_t& near_tri) {
     // aux: the runner-up (a hit code), or AUX_NEAR_BIT | triangle: a candidate at t ~ 0 that the f32 traversal could not rank
     // (k_closest_hit's leaf step); code may then be HIT_MISS.  A candidate the f64 test rejects never wins.
-    const uint32_t code2 = (aux >> 30) == 1u ? (aux & SRC_PRIM_MASK) : aux;
+    const uint32_t code2 = strip_hit((aux >> 30) == 1u ? (aux & SRC_PRIM_MASK) : aux);
     const double none = __builtin_inf();
     const double ta = code == HIT_MISS ? none : ref_t64(sc, code, o64, d64), tb = ref_t64(sc, code2, o64, d64);
     if (code == HIT_MISS) return tb < none ? code2 : HIT_MISS;
@@ -974,11 +990,26 @@ __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t cod
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
-template <bool TRIS>
+template <bool TRIS, bool PRIMARY>   // PRIMARY: iteration 0, the queue holds 16-byte primary rays (k_raygen)
 __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
                                                uint32_t capacity) {
     __shared__ uint32_t lds_alloc[17];
+    // RT_SHADE_SORT (off: measured and dropped, kept as a variant).  The rays of a block round sorted by what they hit before they
+    // are shaded (scenes with triangles): a triangle hit costs two evaluations of the reference's f64 determinants (hit point,
+    // re-hit test), a sphere hit the f64 quadratic, a plane hit or a miss next to nothing, and a wave pays for every kind one of
+    // its 64 lanes holds (VALU lane utilisation of this kernel on C5: 0.49).  A counting sort over the block's 1024 rays by class
+    // (the hit code names it: HIT_PLANE_BIT, HIT_SPHERE_BIT) through LDS makes all but three waves of a block homogeneous; the
+    // queue words travel with the ray (56 bytes each), the slot it came from in lds_i.  Correct (whole GPU suite green), and
+    // slower: C5 28.0 -> 28.4 ms per step, C4 120.7 -> 123.8 (same-box A/B): the kernel waits on memory, not on its VALU work,
+    // and two more barriers and 112 KB of LDS traffic per round cost more than the divergence they remove.
+    constexpr bool SORT = TRIS && RT_SHADE_SORT;
+    constexpr uint32_t SN = SORT ? SHADE_THREADS : 1, SN2 = SORT && !PRIMARY ? SHADE_THREADS : 1;
+    __shared__ float4 lds_a[SN], lds_b[SN2], lds_c[SN2];
+    __shared__ float2 lds_h[SN];
+    __shared__ uint16_t lds_i[SN];
+    __shared__ uint32_t lds_cnt[2][64];   // [round parity][class * 16 + wave]
+    uint32_t parity = 0;
     const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
     const uint32_t n_pad = (n + (SHADE_THREADS - 1)) & ~(uint32_t)(SHADE_THREADS - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -989,7 +1020,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
     float2 nH = make_float2(0.f, 0.f);
     auto load_round = [&](uint32_t j) {
         nA = qi.a[j]; nH = hits[j];
-        if (it != 0) { nB = qi.b[j]; nC = qi.c[j]; }
+        if (!PRIMARY) { nB = qi.b[j]; nC = qi.c[j]; }
     };
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (RT_SHADE_PREFETCH && i < n) load_round(i);
@@ -1000,30 +1031,68 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         bool has_p64 = false;    // ... or on a plane (scenes with triangles): p64 is the f64 hit point, the rays that leave carry it
         f3 p = mk(0, 0, 0), ndir = mk(0, 0, 0), thr = mk(0, 0, 0);
         d3 p64 = mkd(0, 0, 0);
-        uint32_t rng = 0, pid = 0, code = HIT_MISS, dh = 0;
+        uint32_t rng = 0, pid = 0, code = HIT_INVALID, dh = 0;
         uint32_t near_tri = HIT_MISS;   // a triangle coplanar with the hit that lost the f64 comparison (see the tie resolution below)
+        f3 rad = mk(0, 0, 0);    // what the path's end contributes (miss: background, emitter: its colour; absorbed or out of bounces: black)
+        bool has_rad = false;
         bool dir_exact = false;  // the scattered direction is the reference's f64 one: ndir holds its upper bits, d_lo the lower ones (RayQueue::f)
         uint32_t d_lo_x = 0, d_lo_y = 0, d_lo_z = 0;
-        if (i < n) {
-            if (!RT_SHADE_PREFETCH) load_round(i);
-            const float4 A = nA;
-            const float2 H = nH;
+        if (!RT_SHADE_PREFETCH && i < n) load_round(i);
+        float4 A = nA, B = nB, C = nC;
+        float2 H = nH;
+        uint32_t my = i;                                  // the queue slot of the ray this thread shades
+        if (!(i < n)) H = make_float2(__uint_as_float(HIT_MISS), __uint_as_float(HIT_INVALID));
+        if (SORT) {
+            const uint32_t raw = __float_as_uint(H.y), aux = __float_as_uint(H.x);
+            // 0: triangle, or two candidates to decide between (resolve_tie); 1: sphere; 2: plane; 3: miss, padding slot
+            const uint32_t cls = raw == HIT_INVALID ? 3u : aux != HIT_MISS ? 0u : raw == HIT_MISS ? 3u : (raw & HIT_PLANE_BIT) ? 2u : (raw & HIT_SPHERE_BIT) ? 1u : 0u;
+            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+            const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
+            if (lane < 4u) lds_cnt[parity][lane * 16u + wave] = lane == 0u ? c0 : lane == 1u ? c1 : lane == 2u ? c2 : 64u - c0 - c1 - c2;
+            __syncthreads();
+            // every wave scans the 64 counts itself (class-major, so the running sum is the sorted position)
+            const uint32_t cnt = lds_cnt[parity][lane];
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off);
+                if (lane >= (uint32_t)off) incl += v;
+            }
+            parity ^= 1u;
+            // a block of one class (all sky, all ground) is left as it is
+            const uint32_t t0 = __shfl(incl, 15), t1 = __shfl(incl, 31), t2 = __shfl(incl, 47);
+            const bool mixed = !(t0 == SHADE_THREADS || t1 - t0 == SHADE_THREADS || t2 - t1 == SHADE_THREADS || t2 == 0u);
+            if (mixed) {
+                const uint32_t base = __shfl(incl - cnt, (int)(cls * 16u + wave));
+                const uint64_t mine = cls == 0u ? m0 : cls == 1u ? m1 : cls == 2u ? m2 : ~(m0 | m1 | m2);
+                const uint32_t dest = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                lds_a[dest] = A; lds_h[dest] = H; lds_i[dest] = (uint16_t)threadIdx.x;
+                if (!PRIMARY) { lds_b[dest] = B; lds_c[dest] = C; }
+                __syncthreads();
+                A = lds_a[threadIdx.x]; H = lds_h[threadIdx.x];
+                if (!PRIMARY) { B = lds_b[threadIdx.x]; C = lds_c[threadIdx.x]; }
+                my = i - threadIdx.x + lds_i[threadIdx.x];
+            }
+        }
+        if (__float_as_uint(H.y) != HIT_INVALID) {
             f3 o, d;
             uint32_t src = SRC_NONE;
-            if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
+            if (PRIMARY) {   // primary ray: (d, rng) only, see k_raygen
                 o = mk(sc.eye[0], sc.eye[1], sc.eye[2]); d = mk(A.x, A.y, A.z);
-                pid = i;
+                pid = my;
                 thr = mk(1.f, 1.f, 1.f);
                 rng = __float_as_uint(A.w);
             } else {
-                const float4 B = nB, C = nC;
                 o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
                 src = __float_as_uint(B.z);
                 pid = __float_as_uint(B.w);
                 thr = mk(C.x, C.y, C.z);
                 rng = __float_as_uint(C.w);
             }
-            code = __float_as_uint(H.y);
+            code = strip_hit(__float_as_uint(H.y));
+            const bool sphere_hit_ = TRIS ? (__float_as_uint(H.y) & HIT_SPHERE_BIT) != 0u && code < SRC_SPECIAL && !(code & HIT_PLANE_BIT) : true;
+            (void)sphere_hit_;
             float u = 0.f, v = 0.f;
             // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
             // that left a triangle, a plane or a sphere (SRC_E_BIT), a dithered f32 origin otherwise; the carried f64
@@ -1032,23 +1101,23 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             uint32_t sw = 0;
             auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
                 dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
-                const bool carried = it != 0 && src < SRC_SPECIAL && (src & SRC_E_BIT);
+                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT);
                 uint4 E = make_uint4(0u, 0u, 0u, 0u);
-                if (carried) E = qi.e[i];
-                if (it == 0) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
+                if (carried) E = qi.e[my];
+                if (PRIMARY) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
                 else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                 else o64 = dither64(o, dh);
-                if (RT_PRIMARY_REF64 && it == 0 && (flat || RT_PRIMARY_REF64 > 1)) {
+                if (RT_PRIMARY_REF64 && PRIMARY && (flat || RT_PRIMARY_REF64 > 1)) {
                     // in the reference a primary direction is a unit vector to 1e-16 with the bits of its own f64
                     // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
                     // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
                     // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
-                    const uint4 E0 = qi.e[i];
+                    const uint4 E0 = qi.e[my];
                     d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
                 } else {
                     const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
                     uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
-                    if (exact_d || self_ray) F = qi.f[i];
+                    if (exact_d || self_ray) F = qi.f[my];
                     if (exact_d) d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
                     else d64 = dither64(d, dh);
                     if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
@@ -1064,7 +1133,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 // the hit's records, so that they do not wait for the queue word of the f64 ray.)
                 // The same for a candidate at t ~ 0 (AUX_NEAR_BIT): the hit may then have been a miss so far.
                 const uint32_t code2 = __float_as_uint(H.x);
-                if (RT_TIE_SHADE && code != HIT_INVALID && code2 != HIT_MISS && code2 != code) {
+                if (RT_TIE_SHADE && code != HIT_INVALID && code2 != HIT_MISS && strip_hit(code2) != code) {
                     d3 o64t;
                     ray64(o64t, true);
                     code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
@@ -1073,7 +1142,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             if (code == HIT_INVALID) {
                 // padding slot: not a ray
             } else if (code == HIT_MISS) {
-                add_radiance(sc, radiance, pid, thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]));   // raytrace.rs:95
+                rad = thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]); has_rad = true;   // raytrace.rs:95
             } else {
                 float t = H.x;
                 f3 nrm;
@@ -1192,7 +1261,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 f3 albedo = mk(M0.x, M0.y, M0.z);
                 bool scattered = false;
                 if (mtype == 4) {                                   // Emissive, materials.rs:80-88
-                    add_radiance(sc, radiance, pid, thr * albedo);  // raytrace.rs:90
+                    rad = thr * albedo; has_rad = true;             // raytrace.rs:90
                 } else if (mtype == 0) {                            // Lambertian, materials.rs:52-66
                     f3 dir = nrm + random_unit_vector(rng);
                     if (near_zero(dir)) dir = nrm;
@@ -1250,7 +1319,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 } else {                                            // Texture, materials.rs:233-253
                     albedo = texture_albedo(sc, __float_as_int(M1.y), u, v);
                     if (dot(d, nrm) > 0.f) {
-                        add_radiance(sc, radiance, pid, thr * albedo);   // back face emits the texel
+                        rad = thr * albedo; has_rad = true;              // back face emits the texel
                     } else {
                         f3 dir = nrm + random_unit_vector(rng);
                         if (near_zero(dir) || dot(nrm, dir) <= 0.f) dir = nrm;
@@ -1272,6 +1341,19 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         }
                     }
                 }
+            }
+        }
+        if (code != HIT_INVALID) {
+            if (sc.n_lights == 0) {
+                // without lights a path contributes exactly once, when it ends: ONE plain 16-byte store per path, black included
+                // (k_raygen then need not clear the word: 16 bytes per path less)
+                if (!emit) radiance[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
+            } else if (has_rad) {
+                // shadow rays of one path end in different lanes / launches
+                float* r = reinterpret_cast<float*>(radiance + pid);
+                atomicAdd(r + 0, rad.x);
+                atomicAdd(r + 1, rad.y);
+                atomicAdd(r + 2, rad.z);
             }
         }
         // A ray that leaves a triangle: does it re-hit that triangle at t ~ 0?  (intersections.rs:166 has no epsilon;
@@ -1423,8 +1505,8 @@ __global__ __launch_bounds__(256) void k_hit_info(DevScene sc, PassParams pp, Ra
     const size_t px = (size_t)row * sc.width + x;
     if (dout) { dout[px * 3 + 0] = D.x; dout[px * 3 + 1] = D.y; dout[px * 3 + 2] = D.z; }   // the ray k_raygen made (rt_primary_rays)
     if (!obj) return;
-    uint32_t code = __float_as_uint(H.y);
-    if (sc.n_tris && __float_as_uint(H.x) != HIT_MISS && __float_as_uint(H.x) != code) {   // runner-up or candidate at t ~ 0: as in k_shade
+    uint32_t code = strip_hit(__float_as_uint(H.y));
+    if (sc.n_tris && __float_as_uint(H.x) != HIT_MISS && strip_hit(__float_as_uint(H.x)) != code) {   // runner-up or candidate at t ~ 0: as in k_shade
         const d3 d64 = mkd((double)A.w, (double)B.x, (double)B.y);   // (the f32 ray rt_primary_rays reports, as for the triangle's t below)
         uint32_t near_tri = HIT_MISS;
         code = resolve_tie(sc, code, __float_as_uint(H.x), mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]), d64, near_tri);
@@ -1518,8 +1600,14 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
-    if (sc.n_tris) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SHADE_THREADS), 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    const dim3 g(blocks), b(SHADE_THREADS);
+    if (sc.n_tris) {
+        if (it == 0) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+        else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    } else {
+        if (it == 0) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+        else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+    }
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);
