@@ -113,9 +113,11 @@ typedef struct rt_render_params {
     uint32_t sample_end;     /* (anti_aliasing.rs:96-100); end = 0 means N*N             */
     uint32_t tile_index;     /* 8x8-pixel tiles are dealt round-robin: this call renders */
     uint32_t tile_count;     /* tiles t with t % tile_count == tile_index; 0 means 1     */
-    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths = 17 GB of queues; less */
-                                     /* with more than 4 lights: a queue holds one ray per */
-                                     /* light and path)                                    */
+    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths; the wavefront state is   */
+                                     /* 16 + 168 * max(1, n_lights) bytes per path: 184 B,  */
+                                     /* 24.7 GB for the default pass; fewer paths with more */
+                                     /* than 4 lights: a queue holds one ray per light and  */
+                                     /* path)                                               */
     uint32_t max_shadow_generations; /* cap of the shadow-ray branching process          */
                                      /* (raytrace.rs:78-85 recursion); 0 = default 16    */
     uint32_t flags;          /* rt_render_flags                                          */
@@ -165,8 +167,9 @@ int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, float*
  * RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, and the call
  * makes no hipMalloc / hipFree / event creation.  Limits, all reported as errors:
  *  - the call is ONE pass: paths = (tiles of the call) * 64 * (samples of the call) must satisfy
- *    13 KiB + paths * (16 + 168 * max(1, n_lights)) bytes <= RT_NOALLOC_SCRATCH_BYTES (about 364,000 paths
- *    without lights, 190,000 with two); split larger frames over several calls by sample range or tile set;
+ *    16 KiB + paths * (16 + 168 * max(1, n_lights)) bytes <= RT_NOALLOC_SCRATCH_BYTES (the control block and the 256-byte
+ *    alignment of the 13 carved arrays included; about 364,000 paths without lights, 190,000 with two); split larger frames
+ *    over several calls by sample range or tile set;
  *  - RT_FLAG_TIMING is refused (it creates events).
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two contexts, two streams)
  * race; calls in one stream are ordered.  Asynchronous on `stream` like rt_render_accumulate. */
@@ -220,10 +223,20 @@ int rt_scene_upload_devices(rt_context* const* ctxs, uint32_t n, const rt_scene_
  * sources must be complete (synchronise their streams first). */
 int rt_accum_reduce(rt_context* dst, float* dst_accum_dev, rt_context* const* src, const float* const* src_accum_dev, uint32_t n_src, void* stream);
 
+/* The same exchange as ONE RCCL collective (ncclReduce(sum, float, root = GPU 0) of the W x H x 3 accumulators):
+ * accum_dev[0] (on ctxs[0]'s GPU) += accum_dev[k], k = 1..n-1, every accum_dev[k] height*width*3 floats on ctxs[k]'s GPU.
+ * The contexts must be on n DISTINCT GPUs (an RCCL communicator has one rank per GPU; n = 1 is a communicator of one rank);
+ * contexts that share a GPU use rt_accum_reduce.  The communicator is created at the first call (ncclCommInitAll over the
+ * contexts' GPUs), kept by ctxs[0] and re-created when the set of GPUs changes.  The frames must be complete; every rank's part
+ * is queued on its context's own stream and the call returns when the reduce has finished on all GPUs.  The frames of the other
+ * contexts are left as they are. */
+int rt_accum_reduce_rccl(rt_context* const* ctxs, float* const* accum_dev, uint32_t n);
+
 /* rt_render_image on n contexts that hold the same scene: split_tiles = 0 splits the samples of the call into
  * contiguous ranges (same RNG keys as one device), 1 deals the call's 8x8 tiles round-robin; one host thread
- * per context renders, then rt_accum_reduce sums the partial frames on ctxs[0]'s GPU, rt_resolve runs there
- * and the result is copied to the host once.  Outputs as rt_render_image. */
+ * per context renders, then the partial frames are summed on ctxs[0]'s GPU -- contexts on distinct GPUs: rt_accum_reduce_rccl
+ * (one RCCL reduce over xGMI); contexts that share a GPU, or a host where the communicator cannot be created: rt_accum_reduce
+ * (peer copies) -- rt_resolve runs there and the result is copied to the host once.  Outputs as rt_render_image. */
 int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render_params* params, int split_tiles, float* accum_host,
                             uint8_t* rgb8_host);
 

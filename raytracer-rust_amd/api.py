@@ -396,6 +396,15 @@ def accum_reduce(dst_ctx, dst_accum, src_contexts, src_accums, stream=None):
         raise RtError(L.rt_last_error(dst_ctx._h).decode())
 
 
+def accum_reduce_rccl(contexts, accums):
+    """rt_accum_reduce_rccl on torch tensors: accums[0] += accums[1:], ONE RCCL reduce over a communicator of the contexts' GPUs
+    (one rank per GPU: the contexts must be on distinct GPUs).  The tensors must be complete (synchronise first); synchronous."""
+    L = _lib.load_library()
+    ptrs = (C.c_void_p * len(accums))(*[a.data_ptr() for a in accums])
+    if L.rt_accum_reduce_rccl(_ctx_array(contexts), ptrs, len(accums)):
+        raise RtError(L.rt_last_error(contexts[0]._h).decode())
+
+
 def write_png(path, rgb8):
     L = _lib.load_library()
     a = _arr(rgb8, np.uint8)

@@ -205,7 +205,11 @@ void build_bvh(const std::vector<PrimBox>& boxes, Bvh& out, int threads) {
     if (const char* e = getenv("RTAMD_MAX_LEAF")) { max_leaf = (uint32_t)std::min(8, std::max(1, atoi(e))); leaf_dp = false; }   // tuning experiments only: fixed leaf size
     Builder B(boxes, out.order, max_leaf);
     std::vector<TmpNode> tmp;
-    if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads <= 0) {
+        threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        // RTAMD_BVH_THREADS: cap for hosts whose cores are shared by several ranks (bench.py: cores / world size)
+        if (const char* e = getenv("RTAMD_BVH_THREADS")) threads = std::max(1, std::min(threads, atoi(e)));
+    }
 
     if (n < 65536 || threads == 1) {
         tmp.reserve(2 * (size_t)n / 2 + 16);

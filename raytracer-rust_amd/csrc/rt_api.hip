@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/rtamd.h"
 #include "bvh.h"
 #include "rt_kernels.h"
@@ -67,6 +69,10 @@ struct rt_context {
     float* staging = nullptr;      // landing buffer of peer copies
     size_t own_accum_values = 0, staging_values = 0;
     void* scratch_ptr = nullptr;   // device address of `scratch` on this context's GPU
+    // RCCL communicator of a group of contexts (rt_accum_reduce_rccl), kept by the group's first context: one rank per GPU
+    std::vector<ncclComm_t> comms;
+    std::vector<int> comm_devices;
+    bool rccl_unavailable = false; // communicator creation failed once: rt_render_image_devices stays with peer copies
 
     // timing of closest-hit launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -230,6 +236,7 @@ void rt_context_destroy(rt_context* ctx) {
     (void)hipFree(ctx->stats_dev);
     (void)hipFree(ctx->own_accum);
     (void)hipFree(ctx->staging);
+    for (ncclComm_t c : ctx->comms) (void)ncclCommDestroy(c);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -540,7 +547,12 @@ extern "C" int rt_scene_upload_devices(rt_context* const* ctxs, uint32_t n, cons
         FlatScene f;
         if (flatten_scene(ctxs[0], d, f, err)) return fail(ctxs[0], "%s", err.c_str());
         for (uint32_t k = 0; k < n; ++k)
-            if (upload_flat(ctxs[k], f)) { if (k) fail(ctxs[0], "context %u: %s", k, ctxs[k]->error.c_str()); return 1; }
+            if (upload_flat(ctxs[k], f)) {
+                if (k) fail(ctxs[0], "context %u: %s", k, ctxs[k]->error.c_str());
+                // all or nothing: no context of the group is left with the new scene while another holds the old one
+                for (uint32_t j = 0; j < n; ++j) { DeviceGuard g(ctxs[j]->device); (void)hipDeviceSynchronize(); free_scene(ctxs[j]); }
+                return 1;
+            }
         return 0;
     } catch (const std::exception& e) {   // bad_alloc / length_error of the host-side staging: no exception crosses the ABI
         return fail(ctxs[0], "scene upload failed: %s", e.what());
@@ -632,7 +644,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
         uint32_t max_paths = p->max_paths_per_pass ? p->max_paths_per_pass : std::max<uint32_t>(1u << 20, (1u << 27) / std::max(1u, per_path / 4u));
         max_paths = std::max<uint32_t>(64, max_paths & ~63u);
         // tiles per pass / samples per pass.  With the default pass size a device that cannot hold the
-        // queues (>= 120 B per path) gets smaller passes instead of an error.
+        // queues (16 + 168 * max(1, lights) bytes per path: 184 B, 24.7 GB for the default pass) gets smaller passes instead of an error.
         uint64_t cap64;
         for (;;) {
             tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
@@ -888,6 +900,53 @@ int rt_accum_reduce(rt_context* dst, float* dst_accum_dev, rt_context* const* sr
     return 0;
 }
 
+// communicator over the GPUs of ctxs[0..n), one rank per context, kept by ctxs[0] until the set of GPUs changes
+static int ensure_comms(rt_context* root, rt_context* const* ctxs, uint32_t n) {
+    std::vector<int> devs(n);
+    for (uint32_t k = 0; k < n; ++k) devs[k] = ctxs[k]->device;
+    if (root->comm_devices == devs && root->comms.size() == n) return 0;
+    for (ncclComm_t c : root->comms) (void)ncclCommDestroy(c);
+    root->comms.clear(); root->comm_devices.clear();
+    std::vector<ncclComm_t> comms(n, nullptr);
+    const ncclResult_t r = ncclCommInitAll(comms.data(), (int)n, devs.data());
+    if (r != ncclSuccess) return fail(root, "ncclCommInitAll over %u GPUs failed: %s", n, ncclGetErrorString(r));
+    root->comms = comms; root->comm_devices = devs;
+    return 0;
+}
+
+int rt_accum_reduce_rccl(rt_context* const* ctxs, float* const* accum_dev, uint32_t n) {
+    if (!ctxs || n == 0 || !ctxs[0]) return fail(nullptr, "ctxs is NULL or empty");
+    rt_context* root = ctxs[0];
+    if (!accum_dev) return fail(root, "accum_dev is NULL");
+    if (!root->have_scene) return fail(root, "no scene uploaded");
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!ctxs[k] || !accum_dev[k]) return fail(root, "context or frame %u is NULL", k);
+        if (!ctxs[k]->have_scene || ctxs[k]->sc.width != root->sc.width || ctxs[k]->sc.height != root->sc.height)
+            return fail(root, "context %u renders a different frame size", k);
+        for (uint32_t j = 0; j < k; ++j)
+            if (ctxs[j]->device == ctxs[k]->device)
+                return fail(root, "contexts %u and %u are on the same GPU (%d): an RCCL communicator has one rank per GPU; use rt_accum_reduce", j, k, ctxs[k]->device);
+    }
+    try {
+        if (ensure_comms(root, ctxs, n)) return 1;
+        const size_t count = (size_t)root->sc.width * root->sc.height * 3;
+        // ONE reduce(sum, f32) of the frame to the first context's GPU; every rank's part is queued on its context's own stream
+        ncclResult_t r = ncclGroupStart();
+        for (uint32_t k = 0; k < n && r == ncclSuccess; ++k)
+            r = ncclReduce(accum_dev[k], accum_dev[k], count, ncclFloat, ncclSum, 0, root->comms[k], ctxs[k]->own_stream);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return fail(root, "ncclReduce failed: %s", ncclGetErrorString(r));
+        for (uint32_t k = 0; k < n; ++k) {
+            DeviceGuard g(ctxs[k]->device);
+            HIP_TRY(root, hipStreamSynchronize(ctxs[k]->own_stream));
+        }
+    } catch (const std::exception& ex) {
+        return fail(root, "RCCL reduce failed: %s", ex.what());
+    }
+    return 0;
+}
+
 int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render_params* params, int split_tiles, float* accum_host, uint8_t* rgb8_host) {
     if (!ctxs || n == 0 || !ctxs[0]) return fail(nullptr, "ctxs is NULL or empty");
     rt_context* root = ctxs[0];
@@ -906,9 +965,10 @@ int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render
         std::vector<int> rcs(n, 0);
         std::vector<unsigned long long> before(n, 0);
         std::vector<std::thread> threads;
-        for (uint32_t k = 0; k < n; ++k)
-            threads.emplace_back([&, k]() {
-                rt_context* c = ctxs[k];
+        threads.reserve(n);
+        auto body = [&](uint32_t k) {
+            rt_context* c = ctxs[k];
+            try {
                 DeviceGuard g(c->device);
                 rt_render_params p = *params;
                 bool work = true;
@@ -933,16 +993,43 @@ int rt_render_image_devices(rt_context* const* ctxs, uint32_t n, const rt_render
                     hipError_t e = hipStreamSynchronize(c->own_stream);
                     if (e != hipSuccess) rcs[k] = fail(c, "render failed: %s", hipGetErrorString(e));
                 }
-            });
+            } catch (...) {          // (bad_alloc of an error string included: nothing leaves a thread, std::terminate would cross the ABI)
+                rcs[k] = 1;
+            }
+        };
+        try {
+            for (uint32_t k = 0; k < n; ++k) threads.emplace_back(body, k);
+        } catch (const std::exception& e) {
+            for (auto& t : threads) t.join();     // the threads that did start finish before the error is reported
+            return fail(root, "could not start a host thread per device: %s", e.what());
+        }
         for (auto& t : threads) t.join();
         for (uint32_t k = 0; k < n; ++k)
             if (rcs[k]) return k ? fail(root, "device %d: %s", ctxs[k]->device, ctxs[k]->error.c_str()) : 1;
         // exchange: the partial frames are summed on the first context's GPU (peer copies + adds), resolved there
         // (raytrace.rs:144-150, image.rs:37-43) and copied to the host once
         DeviceGuard g(root->device);
-        std::vector<const float*> parts;
-        for (uint32_t k = 1; k < n; ++k) parts.push_back(ctxs[k]->own_accum);
-        if (n > 1 && rt_accum_reduce(root, root->own_accum, ctxs + 1, parts.data(), n - 1, root->own_stream)) return 1;
+        if (n > 1) {
+            // contexts on n distinct GPUs: one RCCL reduce over xGMI; contexts that share a GPU (or a host where the communicator
+            // cannot be created): peer copies into a landing buffer + adds on the first GPU
+            bool distinct = true;
+            for (uint32_t k = 0; k < n; ++k) for (uint32_t j = 0; j < k; ++j) distinct = distinct && ctxs[j]->device != ctxs[k]->device;
+            bool done = false;
+            if (distinct && !root->rccl_unavailable) {
+                std::vector<float*> frames(n);
+                for (uint32_t k = 0; k < n; ++k) frames[k] = ctxs[k]->own_accum;
+                if (rt_accum_reduce_rccl(ctxs, frames.data(), n) == 0) done = true;
+                else if (root->comms.empty()) {
+                    root->rccl_unavailable = true;
+                    fprintf(stderr, "rtamd: %s; the partial frames are summed over peer copies instead\n", root->error.c_str());
+                } else return 1;
+            }
+            if (!done) {
+                std::vector<const float*> parts;
+                for (uint32_t k = 1; k < n; ++k) parts.push_back(ctxs[k]->own_accum);
+                if (rt_accum_reduce(root, root->own_accum, ctxs + 1, parts.data(), n - 1, root->own_stream)) return 1;
+            }
+        }
         uint8_t* rgb8 = nullptr;
         int rc = 0;
         do {

@@ -55,7 +55,7 @@ class StatsC(C.Structure):
 # every symbol the headers declare (tests/test_host.py::test_library_exports_every_declared_symbol and tests/test_abi.py)
 ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_render_accumulate", "rt_resolve",
-    "rt_render_image", "rt_primary_hits", "rt_primary_rays", "rt_render_accumulate_noalloc", "rt_scene_upload_devices", "rt_accum_reduce",
+    "rt_render_image", "rt_primary_hits", "rt_primary_rays", "rt_render_accumulate_noalloc", "rt_scene_upload_devices", "rt_accum_reduce", "rt_accum_reduce_rccl",
     "rt_render_image_devices", "rt_get_stats", "rt_stats_reset", "rt_debug_gather", "rt_context_set_bvh_builder", "rt_bvh_build_validate",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_desc", "rt_host_scene_num_objects", "rt_host_scene_object_kind",
     "rt_host_ssaa_parse", "rt_host_camera", "rt_host_write_png", "rt_host_write_png16", "rt_host_read_png", "rt_host_free", "rt_host_compute_image", "rt_host_compute_image_devices", "rt_host_bvh_validate",
@@ -110,6 +110,8 @@ def load_library():
     L.rt_scene_upload_devices.argtypes = [C.POINTER(vp), u32, C.POINTER(SceneDesc)]
     L.rt_accum_reduce.restype = C.c_int
     L.rt_accum_reduce.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u32, vp]
+    L.rt_accum_reduce_rccl.restype = C.c_int
+    L.rt_accum_reduce_rccl.argtypes = [C.POINTER(vp), C.POINTER(vp), u32]
     L.rt_render_image_devices.restype = C.c_int
     L.rt_render_image_devices.argtypes = [C.POINTER(vp), u32, C.POINTER(RenderParamsC), C.c_int, vp, vp]
     L.rt_get_stats.restype = C.c_int

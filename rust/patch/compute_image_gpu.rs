@@ -4,6 +4,19 @@
 //! reference: `pub` getters for the four private `Camera` fields (camera.rs:7-12), `pub` access to the
 //! material fields (materials.rs:40-43,68-71,90-94,155-159), `image::read_image_bytes` (the decoding half of
 //! image.rs:166-173: the raw RGB8 bytes before `Color::from_output`) and `image::write_rgb8` below.
+//! `read_image_bytes`, to be added to src/raytracer/image.rs beside `read_image` (it is that function up to the byte buffer):
+//!
+//! ```ignore
+//! pub fn read_image_bytes(file_path: &std::path::Path) -> (Vec<u8>, usize, usize) {
+//!     let file = fs::File::open(file_path).unwrap();
+//!     let decoder = png::Decoder::new(file);
+//!     let mut reader = decoder.read_info().unwrap();
+//!     let mut buf = vec![0; reader.output_buffer_size()];
+//!     let info = reader.next_frame(&mut buf).unwrap();
+//!     buf.truncate(info.buffer_size());
+//!     (buf, info.width as usize, info.height as usize)
+//! }
+//! ```
 //! The flattening mirrors `load_scene()` in raytracer-rust_amd/csrc/rt_host.cpp, which is the tested
 //! statement of the same logic.
 use rtamd_sys::*;
@@ -29,7 +42,7 @@ fn push_material(f: &mut Flat, m: &Material) -> i32 {
             // The library wants the decoded PNG bytes themselves (it applies byte / 255.999 on fetch, image.rs:45-51).
             // They are read again from texture_path: rebuilding them from pixel_colors with to_output() is NOT exact,
             // because to_output truncates (image.rs:37-43) and trunc(255.999 * (b / 255.999)) can come out as b - 1.
-            let (bytes, w, h) = image::read_image_bytes(Path::new(&tm.texture_path));   // Vec<u8> of w * h * 3
+            let (bytes, w, h) = image::read_image_bytes(std::path::Path::new(&tm.texture_path));   // Vec<u8> of w * h * 3
             f.tex_w.push(w as u32);
             f.tex_h.push(h as u32);
             f.tex_data.push(bytes);

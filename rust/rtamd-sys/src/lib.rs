@@ -113,6 +113,7 @@ extern "C" {
     pub fn rt_render_accumulate_noalloc(ctx: *mut rt_context, params: *const rt_render_params, accum_dev: *mut f32, stream: *mut c_void) -> c_int;
     pub fn rt_scene_upload_devices(ctxs: *const *mut rt_context, n: u32, scene: *const rt_scene_desc) -> c_int;
     pub fn rt_accum_reduce(dst: *mut rt_context, dst_accum_dev: *mut f32, src: *const *mut rt_context, src_accum_dev: *const *const f32, n_src: u32, stream: *mut c_void) -> c_int;
+    pub fn rt_accum_reduce_rccl(ctxs: *const *mut rt_context, accum_dev: *const *mut f32, n: u32) -> c_int;
     pub fn rt_render_image_devices(ctxs: *const *mut rt_context, n: u32, params: *const rt_render_params, split_tiles: c_int, accum_host: *mut f32, rgb8_host: *mut u8) -> c_int;
     pub fn rt_get_stats(ctx: *mut rt_context, out: *mut rt_stats) -> c_int;
     pub fn rt_stats_reset(ctx: *mut rt_context) -> c_int;

@@ -259,6 +259,20 @@ int main() {
         HIP(hipStreamSynchronize(stream));
         HIP(hipMemcpy(acc2.data(), acc_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));
         CHECK(max_rel_diff(acc, acc2) <= 1e-5);
+        {   // the same exchange as an RCCL collective: a communicator of one rank leaves the frame as it is; two contexts on one
+            // GPU are refused (one rank per GPU)
+            rt_context* one[1] = {ctx};
+            float* frame[1] = {acc_dev};
+            OK(ctx, rt_accum_reduce_rccl(one, frame, 1));
+            OK(ctx, rt_accum_reduce_rccl(one, frame, 1));   // (the communicator is kept)
+            std::vector<float> acc3(npx * 3);
+            HIP(hipMemcpy(acc3.data(), acc_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            CHECK(acc3 == acc2);
+            rt_context* same[2] = {ctx, ctx2};
+            float* frames[2] = {acc_dev, acc_dev2};
+            FAILS(ctx, rt_accum_reduce_rccl(same, frames, 2));
+            FAILS(ctx, rt_accum_reduce_rccl(one, nullptr, 1));
+        }
         rt_context_destroy(ctx2);
         HIP(hipFree(acc_dev2));
         HIP(hipFree(acc_dev)); HIP(hipFree(col_dev)); HIP(hipFree(rgb_dev));

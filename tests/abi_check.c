@@ -97,6 +97,7 @@ _Static_assert(sizeof(void*) == 8 && sizeof(size_t) == 8, "LP64 expected");
 /* every entry point is declared with a C-compatible signature (an unevaluated use: nothing is linked) */
 #define DECLARED(f) _Static_assert(sizeof(&f) == sizeof(void (*)(void)), #f " is not declared")
 DECLARED(rt_accum_reduce);
+DECLARED(rt_accum_reduce_rccl);
 DECLARED(rt_bvh_build_validate);
 DECLARED(rt_context_create);
 DECLARED(rt_context_destroy);
@@ -128,7 +129,7 @@ DECLARED(rt_resolve);
 DECLARED(rt_scene_upload);
 DECLARED(rt_scene_upload_devices);
 DECLARED(rt_stats_reset);
-#define N_ENTRY_POINTS 32
+#define N_ENTRY_POINTS 33
 
 #define P_STRUCT(T) printf("%s\"" #T "\": {\"size\": %zu, \"fields\": [", first_struct ? "" : ", ", sizeof(T)); first_struct = 0; first_field = 1
 #define P_FIELD(T, f) printf("%s[\"" #f "\", %zu, %zu]", first_field ? "" : ", ", offsetof(T, f), sizeof(((T*)0)->f)); first_field = 0

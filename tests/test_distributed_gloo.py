@@ -80,16 +80,19 @@ def test_bench_step_partition_is_disjoint_and_complete(world):
     """bench.py's per-step partition (distributed.bench_step_params), without a GPU: under the sample split the cell
     ranges of the ranks of one step are disjoint, and 4096 / (64 * world) steps cover the 64x64 grid exactly once;
     under the tile split every rank traces the same cells and the tile masks are disjoint and cover the frame."""
-    grid_n, spp = 64, 64
-    seen = np.zeros(grid_n * grid_n, int)
-    steps = grid_n * grid_n // (spp * world)
-    for k in range(steps):
-        ranges = [D.bench_step_params(k, r, world, spp, grid_n, "spp") for r in range(world)]
-        for (b, e, ti, tc) in ranges:
-            assert 0 <= b < e <= grid_n * grid_n and e - b == spp and (ti, tc) == (0, 1)
-            seen[b:e] += 1
-    assert np.all(seen == 1)
-    assert D.bench_step_params(steps, 0, world, spp, grid_n, "spp")[:2] == (0, spp)        # wraps
+    grid_n = 64
+    for spp in (64, 512):          # 512: bench.py's default step, C5's per-GPU share of the 4096-spp frame (at world 8 ONE step is the frame)
+        seen = np.zeros(grid_n * grid_n, int)
+        steps = grid_n * grid_n // (spp * world)
+        assert spp != 512 or world != 8 or steps == 1
+        for k in range(steps):
+            ranges = [D.bench_step_params(k, r, world, spp, grid_n, "spp") for r in range(world)]
+            for (b, e, ti, tc) in ranges:
+                assert 0 <= b < e <= grid_n * grid_n and e - b == spp and (ti, tc) == (0, 1)
+                seen[b:e] += 1
+        assert np.all(seen == 1)
+        assert D.bench_step_params(steps, 0, world, spp, grid_n, "spp")[:2] == (0, spp)        # wraps
+    spp = 64
     for k in (0, 5):
         ps = [D.bench_step_params(k, r, world, spp, grid_n, "tiles") for r in range(world)]
         assert len({p[:2] for p in ps}) == 1 and [p[2:] for p in ps] == [(r, world) for r in range(world)]

@@ -226,7 +226,48 @@ def test_accum_reduce_on_device_tensors(ctx):
     assert torch.equal(a.cpu(), torch.arange(27, dtype=torch.float32).reshape(3, 3, 3) + 1)
 
 
-@pytest.mark.parametrize("ranks,workload,scaling", [(2, "c5", "weak"), (3, "c4", "strong")])
+def test_accum_reduce_rccl_communicator(ctx):
+    """rt_accum_reduce_rccl: the exchange step as ONE RCCL reduce on a communicator the library creates over the contexts' GPUs
+    (librtamd.so links librccl.so).  This box has one GPU, so the communicator has one rank: creation, reuse, the collective call
+    on the context's stream and the refusal of two contexts on one GPU are what runs here; with two or more GPUs the test also
+    renders a frame on every GPU and compares the RCCL sum (and rt_render_image_devices, which then takes this path) with one GPU."""
+    import torch
+    load_extra(ctx, "two_objects")
+    a = torch.rand((ctx.height, ctx.width, 3), generator=torch.Generator().manual_seed(3)).cuda()
+    want = a.clone()
+    torch.cuda.synchronize()
+    rt.accum_reduce_rccl([ctx], [a])
+    rt.accum_reduce_rccl([ctx], [a])             # the communicator is kept by the context
+    assert torch.equal(a, want)
+    other = rt.Context(0)
+    try:
+        other.upload(ctx.scene)
+        with pytest.raises(rt.RtError, match="same GPU"):
+            rt.accum_reduce_rccl([ctx, other], [a, want])
+    finally:
+        other.close()
+    n = torch.cuda.device_count()
+    if n < 2:
+        return
+    group = [ctx] + [rt.Context(k) for k in range(1, n)]
+    try:
+        rt.upload_devices(group, ctx.scene)
+        p = rt.RenderParams("jitter:4", depth=5, seed=13)
+        one, one_rgb = ctx.render_image(p)
+        for split in ("spp", "tiles"):
+            got, rgb = rt.render_image_devices(group, p, split=split)          # distinct GPUs: rt_accum_reduce_rccl inside
+            assert np.allclose(got, one, rtol=1e-5, atol=1e-6) and np.abs(rgb.astype(int) - one_rgb.astype(int)).max() <= 1, split
+        parts = [torch.full((ctx.height, ctx.width, 3), float(k + 1), device="cuda:%d" % k) for k in range(n)]
+        for k in range(n):
+            torch.cuda.synchronize(k)
+        rt.accum_reduce_rccl(group, parts)
+        assert torch.all(parts[0] == n * (n + 1) / 2) and all(torch.all(parts[k] == k + 1) for k in range(1, n))
+    finally:
+        for c in group[1:]:
+            c.close()
+
+
+@pytest.mark.parametrize("ranks,workload,scaling", [(2, "c5", "weak"), (3, "c4", "strong"), (8, "c5", "weak")])
 def test_bench_multi_rank_control_flow(ranks, workload, scaling, tmp_path):
     """bench.py's N > 1 branch (process group, per-rank partition, reduce to rank 0, max-over-ranks timing, summed ray
     counts) executed end to end with several ranks sharing this box's one GPU: RTAMD_BENCH_REHEARSAL=gloo swaps RCCL for
@@ -241,7 +282,7 @@ def test_bench_multi_rank_control_flow(ranks, workload, scaling, tmp_path):
     env = dict(os.environ, RTAMD_BENCH_REHEARSAL="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--small",
-                        "--workload", workload], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+                        "--workload", workload, "--spp-per-step", "64"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1                                     # rank 0 prints ONE line
@@ -251,6 +292,9 @@ def test_bench_multi_rank_control_flow(ranks, workload, scaling, tmp_path):
     per_step = w * h * 64 * (ranks if scaling == "weak" else 1)          # weak: every rank renders the frame; strong: the ranks share it
     assert j["config"]["paths_per_step"] == per_step
     assert "cpu_baseline" not in j and "other_workloads" not in j         # N = 1 only
+    # what a scaling loss would be attributed with: the ranks' own times per step (before the barrier) and the exchange step
+    assert 0 < j["ranks"]["ms_per_step_min"] <= j["ranks"]["ms_per_step_max"] <= j["ms_per_step"] * 1.05
+    assert j["ranks"]["reduce_bytes"] == w * h * 12
 
 
 def test_c_abi_host_code_under_asan():

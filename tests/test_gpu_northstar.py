@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle_py as O
 from test_gpu_parity import gamma, psnr
-from util import ROOT, pkg, sub
+from util import PARITY, ROOT, pkg, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +47,19 @@ def test_north_star_frame_passes_the_window_gate(tmp_path):
         bias = abs(g.mean() - 0.5 * (a.mean() + b.mean()))
         print("window x %d..%d rows %d..%d: PSNR %.2f dB of the 1024-spp frame against the oracle at 2 x 4096 spp (oracle 4096 vs 4096: %.2f dB), "
               "|bias| %.2e, mean radiance %.3f" % (x0, x1, r0, r1, p, floor, bias, a.mean()))
+        PARITY.setdefault("north_star_frame_1080p_1024spp", {})["window_x%d_row%d" % (x0, r0)] = dict(psnr_db=p, oracle_seed_to_seed_db=floor, abs_bias=bias, mean_radiance=a.mean())
         assert a.mean() > 0.02 and p >= 40.0 and bias <= 1e-3
+    # the WHOLE frame, sparsely: every 16th pixel and row (8,100 pixels) of the 1024-spp frame against the oracle at 4096 spp
+    lat = osc.render_crop((0, osc.width, 0, osc.height), mode="jitter", N=64, depth=5, seed=303, step=16)["sum"][::16, ::16] / 4096.0
+    g = acc[::16, ::16].astype(np.float64) / spp
+    assert lat.shape == g.shape == (68, 120, 3)
+    p = psnr(gamma(g, 1), gamma(lat, 1))
+    bias = abs(g.mean() - lat.mean())
+    print("lattice of %d pixels over the whole frame: PSNR %.2f dB of the 1024-spp frame against the oracle at 4096 spp, |bias| %.2e, mean radiance %.3f"
+          % (g.shape[0] * g.shape[1], p, bias, lat.mean()))
+    PARITY["north_star_frame_1080p_1024spp"]["lattice_every_16th_pixel_and_row"] = dict(pixels=g.shape[0] * g.shape[1], psnr_db=p, abs_bias=bias, mean_radiance=lat.mean())
+    PARITY["north_star_frame_1080p_1024spp"]["info"] = info
+    assert p >= 40.0 and bias <= 1e-3
 
 
 def _dirs(osc, step):

@@ -115,6 +115,7 @@ def test_c2_cube_primary_hits_bit_exact(ctx):
     got2, want2 = hits_pair(ctx, osc, 0.0, 0.0, own_camera_id_slack=0)      # and along the device's f32 rays
     check_hits(got2, want2, allow_id_mismatch=0)
     print("C2: ids exact, max rel t %.2e, normal %.2e" % (rt_, rn))
+    PARITY["primary_hits_c2_cube"] = dict(rays=got["t"].size, id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
 
 
 @pytest.mark.parametrize("off", [(0.5, 0.5), (0.25, 0.75)])
@@ -229,6 +230,7 @@ def test_converged_image_parity(ctx, name, n):
     p = psnr(g, o)
     bias = abs(np.mean(acc / spp) - np.mean(ref["sum"] / spp))
     print("%s: PSNR %.2f dB at %d spp, |mean radiance bias| %.2e" % (name, p, spp, bias))
+    PARITY.setdefault("converged_images", {})["%s 128x128 %d spp" % (name, spp)] = dict(psnr_db=p, abs_bias=bias)
     assert p >= 40.0
     assert bias <= 1e-3
 
@@ -244,6 +246,7 @@ def test_c3_image_parity_small(ctx):
     bias = abs(np.mean(acc) - np.mean(ref["sum"])) / (n * n)
     assert bias <= 1e-3, bias
     print("C3 160x90: PSNR %.2f dB at %d spp" % (p, n * n))
+    PARITY.setdefault("converged_images", {})["c3 160x90 %d spp" % (n * n)] = dict(psnr_db=p, abs_bias=bias)
     assert p >= 40.0
 
 
@@ -262,6 +265,7 @@ def test_c3_image_parity_depth_50(ctx):
     bias = abs(np.mean(acc) - np.mean(ref["sum"])) / (n * n)
     print("C3 128x72 depth 50: PSNR %.2f dB at %d spp, |bias| %.2e, %.2f rays per path (oracle %.2f)"
           % (p, n * n, bias, st["rays_total"] / st["paths"], ref["rays"] / (128 * 72 * n * n)))
+    PARITY.setdefault("converged_images", {})["c3 128x72 depth 50 %d spp" % (n * n)] = dict(psnr_db=p, abs_bias=bias, rays_per_path=st["rays_total"] / st["paths"], oracle_rays_per_path=ref["rays"] / (128 * 72 * n * n))
     assert p >= 40.0 and bias <= 1e-3
     assert abs(st["rays_total"] / st["paths"] - ref["rays"] / (128 * 72 * n * n)) < 0.01
 
@@ -277,6 +281,7 @@ def test_c5_image_parity_small(ctx):
     p = psnr(gamma(acc.astype(np.float64), n * n), ref["color"])
     ref2 = osc.render(mode="jitter", N=n, depth=5, seed=24)
     print("C5 128x72 (3.6k tris): PSNR %.2f dB at %d spp (oracle seed-to-seed floor %.2f dB)" % (p, n * n, psnr(ref2["color"], ref["color"])))
+    PARITY.setdefault("converged_images", {})["c5 128x72 3.6k tris %d spp" % (n * n)] = dict(psnr_db=p, oracle_seed_to_seed_db=psnr(ref2["color"], ref["color"]))
     assert p >= 40.0
 
 
@@ -315,6 +320,7 @@ def test_converged_renders_match_the_reference_pngs(ctx):
         gold = np.asarray(Image.open(os.path.join(GOLDEN, "scenes", name, name + ".png")).convert("RGB")).astype(float)
         _, rgb = ctx.render_image(rt.RenderParams("jitter:64", depth=12, seed=11))
         img = rgb.astype(float)
+        PARITY.setdefault("against_the_reference_pngs_4096spp_depth12", {})[name] = dict(psnr_db=psnr(img, gold), psnr_db_box4x4=psnr(box(img), box(gold)), mean_difference_levels=(img - gold).mean())
         assert psnr(img, gold) >= raw_db, (name, psnr(img, gold))
         assert psnr(box(img), box(gold)) >= filtered_db, (name, psnr(box(img), box(gold)))
         assert abs((img - gold).mean()) <= 0.02, (name, (img - gold).mean())
@@ -343,6 +349,9 @@ def _mean_where(ctx, objs, bg, cam, w, h, depth, select, seed, chan=0):
     got = acc.astype(np.float64) / 4096.0
     m = select(osc.primary_hits(0.5, 0.5)["object_id"], want)
     assert m.sum() >= 10
+    import inspect
+    PARITY.setdefault("device_over_oracle_mean_radiance", {}).setdefault(inspect.stack()[1].function, []).append(
+        dict(pixels=int(m.sum()), depth=depth, seed=seed, ratio=got[m][:, chan].mean() / want[m][:, chan].mean() if want[m][:, chan].mean() else None))
     return got[m][:, chan].mean(), want[m][:, chan].mean()
 
 
@@ -491,7 +500,6 @@ def test_three_surfaces_at_one_distance(ctx):
     cam = dict(eye=[0.3, 3.1, 4.9], look_at=[0.0, -0.2, -0.3], up=[0.0, 1.0, 0.0], fovy=35.0)
     for obj in (0, 1, 2):
         got, want = _mean_where(ctx, objs, [0.7, 0.8, 0.9], cam, 48, 36, 5, lambda ids, img: ids == obj, 21 + obj, chan=slice(None))
-        PARITY.setdefault("three_surfaces_at_one_distance", {})["object_%d" % obj] = got / want
         assert abs(got / want - 1.0) < 0.015, (obj, got, want)
 
 
@@ -507,7 +515,6 @@ def test_three_coincident_faces(ctx):
     c = _mesh(_box([-1.25, 0.125, -0.75], [0.25, 1.125, 0.25]), dict(type="Lambertian", albedo=[0.7, 0.4, 0.3]))
     for obj in (0, 1, 2):
         got, want = _mean_where(ctx, [a, b, c], [0.7, 0.8, 0.9], cam, 48, 36, 4, lambda ids, img: ids == obj, 31 + obj, chan=slice(None))
-        PARITY.setdefault("three_coincident_faces", {})["object_%d" % obj] = got / want
         assert abs(got / want - 1.0) < 0.10, (obj, got, want)     # stated deviation, see the docstring
 
 
@@ -532,7 +539,6 @@ def test_a_closed_mesh_room_far_from_the_origin(ctx, offset):
     b2 = _mesh(place(_box([-0.209, 0.017, -1.287], [0.491, 0.521, 0.109])), dict(type="Metal", albedo=[0.8, 0.8, 0.9], fuzziness=0.2))   # ... and against the first box
     cam = dict(eye=list(place([0.7, 1.6, 1.7])), look_at=list(place([-0.4, 0.6, -1.0])), up=list(np.array([0.0, 1.0, 0.0]) @ R.T), fovy=55.0)
     got, want = _mean_where(ctx, [room, lamp, b1, b2], [40.0, 40.0, 40.0], cam, 48, 36, 6, lambda ids, img: ids >= 0, 41, chan=slice(None))
-    PARITY.setdefault("closed_mesh_room", {})["offset_%g" % offset] = got / want
     assert 0.05 < want < 3.0, want          # the oracle's room is lit and closed: nothing of the background gets in
     assert abs(got / want - 1.0) < 0.015, (offset, got, want)
 
@@ -609,6 +615,7 @@ def window_image_parity(ctx, osc, n, windows, depth=5, what=""):
         bias = abs(g.mean() - 0.5 * (a.mean() + b.mean())) / spp
         print("%s window x %d..%d rows %d..%d at %d spp: PSNR %.2f dB (oracle seed-to-seed %.2f), mean-abs %.2e (floor %.2e), |bias| %.2e, mean radiance %.3f"
               % (what, x0, x1, r0, r1, spp, p, floor, mae, mae_floor, bias, a.mean() / spp))
+        PARITY.setdefault("full_size_windows", {})["%s x%d row%d %d spp" % (what, x0, r0, spp)] = dict(psnr_db=p, oracle_seed_to_seed_db=floor, mean_abs=mae, mean_abs_floor=mae_floor, abs_bias=bias)
         assert a.mean() / spp > 0.02                 # the window is lit: a black window would pass any gate
         assert p >= 40.0
         assert mae <= mae_floor + 1e-3
@@ -632,6 +639,7 @@ def test_full_size_c5_hits_image_and_properties(ctx):
     bad, rt_, rn = check_hits(got, want, allow_id_mismatch=int(1e-4 * on_mesh.sum()))     # see test_full_size_c4_hits_and_image
     print("C5 1920x1080, all %d primary rays: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e"
           % (got["t"].size, bad, on_mesh.sum(), rt_, rn))
+    PARITY["primary_hits_c5_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
     rows, cols = np.nonzero(on_mesh)
     r0, c0 = int(np.median(rows)), int(np.median(cols))
     edge_r = int(rows.max()) - 8                                        # lower silhouette of the torus against the ground
@@ -665,6 +673,7 @@ def test_full_size_c3_hits(ctx):
     got, want = hits_pair(ctx, osc, own_camera_id_slack=64)
     bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8)
     print("C3 1920x1080, all %d primary rays: %d id mismatches, max rel t %.2e, normal %.2e" % (got["t"].size, bad, rt_, rn))
+    PARITY["primary_hits_c3_1080p"] = dict(rays=got["t"].size, id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
 
 
 def test_full_size_c4_hits_and_image(ctx):
@@ -682,6 +691,7 @@ def test_full_size_c4_hits_and_image(ctx):
     # neighbouring triangle: the count is reported and bounded at 1 in 10,000 rays on the mesh
     bad, rt_, rn = check_hits(got, want, allow_id_mismatch=int(1e-4 * on_mesh.sum()))
     print("C4 3840x2160, middle 1920x1080: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e" % (bad, on_mesh.sum(), rt_, rn))
+    PARITY["primary_hits_c4_4k_middle_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
     check_hits(*hits_pair(ctx, osc, crop=(0, 400, 0, 2160), own_camera_id_slack=16), allow_id_mismatch=4)
     rows, cols = np.nonzero(on_mesh)
     r0, c0 = 540 + int(np.median(rows)), 960 + int(np.median(cols))

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for kv in "$@"; do
     name=${kv%%=*}; lib=${kv#*=}
-    RTAMD_LIB=$lib timeout -k 10 150 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline ${AB_ARGS:-} > gpurun_out/var_${name}_$rep.log 2>&1 || { echo "$name failed"; tail -5 gpurun_out/var_${name}_$rep.log; exit 1; }
+    RTAMD_LIB=$lib timeout -k 10 150 python3 bench.py --steps 4 --warmup 1 --spp-per-step 64 --no-cpu-baseline --no-other-workloads ${AB_ARGS:-} > gpurun_out/var_${name}_$rep.log 2>&1 || { echo "$name failed"; tail -5 gpurun_out/var_${name}_$rep.log; exit 1; }
     python3 - "$name" gpurun_out/var_${name}_$rep.log <<'PY'
 import json,sys
 for line in open(sys.argv[2]):

@@ -6,7 +6,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/kstats_$TAG
 mkdir -p $OUT
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-mesh-share --no-other-workloads "$@" > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 4 --warmup 1 --spp-per-step 64 --no-cpu-baseline --no-mesh-share --no-other-workloads "$@" > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 python3 - $OUT/kernel_stats.csv <<'PY'

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run_pass() {
   name=$1; shift
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mesh-share $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mesh-share --spp-per-step 64 $BENCH_ARGS > $OUT/$name.log 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   return $rc

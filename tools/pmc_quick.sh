@@ -5,8 +5,8 @@ TAG=$1
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmcq_$TAG
 mkdir -p $OUT
-timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads ${PMC_ARGS:-} > $OUT/sq1.log 2>&1 || exit 1
-timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads ${PMC_ARGS:-} > $OUT/sq2.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 1 --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-other-workloads ${PMC_ARGS:-} > $OUT/sq1.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 1 --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-other-workloads ${PMC_ARGS:-} > $OUT/sq2.log 2>&1 || exit 1
 python3 tools/pmc_summary.py $OUT > $OUT/summary.json
 python3 - $OUT/summary.json <<'PY'
 import json,sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns a tools/pmc_profile.sh run (gpurun_out/pmc_<tag>/) into the per-ray PMC figures bench.py reads:
 
-  python tools/pmc_to_profile.py <workload> gpurun_out/pmc_<tag> [--out profiles/r02_pmc.json]
+  python tools/pmc_to_profile.py <workload> gpurun_out/pmc_<tag> [--out profiles/r03_pmc.json]
 
 Every pass of pmc_profile.sh is `bench.py --steps 1 --warmup 0`: the k_closest_hit<false> dispatches of a pass are the
 launches of the one timed step, whose ray count is in the bench line of the pass's log.  Per-ray figures therefore
@@ -15,7 +15,7 @@ import os
 import sys
 
 workload, root = sys.argv[1], sys.argv[2]
-out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc.json")
+out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc.json")
 summ = json.load(open(os.path.join(root, "summary.json")))
 line = None
 for l in open(os.path.join(root, "sq1.log")):
@@ -26,11 +26,9 @@ res = {}
 for kern in ("k_closest_hit", "k_shade"):
     v = summ[kern]
     n = v["_dispatches"]
-    rays = r["rays_per_launch"] * r["launches"]          # rays of the timed step = what these dispatches traced
-    if kern == "k_shade":
-        # k_shade also runs in bench.py's counters step (same rays once more; only k_closest_hit has a counters variant
-        # that the summary keeps apart): its dispatches cover the rays as many times as they outnumber the timed launches
-        rays *= n / float(r["launches"])
+    # every step of a pass (timed, instrumented; for k_shade also bench.py's counters step, whose k_closest_hit is a variant of
+    # its own that the summary keeps apart) traces the same rays: dispatches x mean rays per launch
+    rays = r["rays_per_launch"] * n
     g = lambda k: v.get(k, 0.0)
     f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
     cycles = 2.0 * g("SQ_INSTS_VALU") + 2.0 * (f64 + g("SQ_INSTS_VALU_TRANS_F32")) + 6.0 * g("SQ_INSTS_VALU_TRANS_F64")
@@ -56,6 +54,9 @@ top = dict(res["k_closest_hit"])
 top["k_shade"] = res["k_shade"]
 top["source"] = "tools/pmc_profile.sh (one rocprofv3 --pmc pass per run of `bench.py --steps 1 --warmup 0 --workload %s`), summary: %s" % (workload, os.path.join(root, "summary.json"))
 top["bench_line_of_the_sq1_pass"] = {"value": line["value"], "ms_per_launch": r["ms_per_launch"], "rays_per_launch": r["rays_per_launch"]}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+top["kernel_hash"] = bench.kernel_hash()      # bench.py flags a profile collected on other kernel sources ("pmc_stale")
 all_[workload] = top
 json.dump(all_, open(out_path, "w"), indent=1)
 print(json.dumps({k: top[k] for k in ("valu_insts_per_ray", "valu_pipe_cycles_per_ray", "fetch_write_bytes_per_ray", "valu_lane_utilisation", "waves_per_simd", "valu_pipe_busy_from_cycles", "wave_time_split")}, indent=1))
