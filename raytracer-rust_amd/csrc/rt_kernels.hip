@@ -38,6 +38,62 @@ __device__ __forceinline__ bool near_zero(f3 v) { return fabsf(v.x) < 1e-8f && f
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Queue words, hit records and sample radiance are written once and read once by a later launch: streamed with the non-temporal
+// cache policy (RT_NT), so that they do not displace the BVH and the shading records from L2 (same-box A/B: C5 27.75 -> 26.96 ms
+// per 64-spp step, C4 120.2 -> 115.8; what IS re-read -- leaf primitives, shading records -- loses with the same policy).
+#ifndef RT_NT
+#define RT_NT 1
+#endif
+
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if RT_NT
+    const v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#if RT_NT
+    const v4u_ v = __builtin_nontemporal_load(reinterpret_cast<const v4u_*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float2 ld_stream(const float2* p) {
+#if RT_NT
+    const v2f_ v = __builtin_nontemporal_load(reinterpret_cast<const v2f_*>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if RT_NT
+    __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+#if RT_NT
+    __builtin_nontemporal_store(v4u_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u_*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(float2* p, float2 v) {
+#if RT_NT
+    __builtin_nontemporal_store(v2f_{v.x, v.y}, reinterpret_cast<v2f_*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // PCG (rxs-m-xs 32): one 32-bit state per path.  The reference's thread_rng stream is not a
 // parity target.
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
@@ -101,6 +157,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #endif
 #ifndef RT_PRIMARY_REFORDER
 #define RT_PRIMARY_REFORDER 1
+#endif
+#ifndef RT_SPHERE_E
+#define RT_SPHERE_E 0
 #endif
 #ifndef RT_TIE_SHADE
 #define RT_TIE_SHADE 1    // 0: k_shade ignores the runner-up (measurements only)
@@ -186,10 +245,10 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
                 // RayQueue::e; forming it again in k_shade costs more than these 16 + 16 bytes: registers)
                 uint4 lo = make_uint4(0u, 0u, 0u, 0u);
                 split64(dx, A.x, lo.x); split64(dy, A.y, lo.y); split64(dz, A.z, lo.z);
-                q.e[pid] = lo;
+                st_stream(&q.e[pid], lo);
             }
         }
-        q.a[pid] = A;
+        st_stream(&q.a[pid], A);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
 }
@@ -601,21 +660,21 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         // A refill is a chain of dependent memory round trips during which the wave's other
                         // lanes wait, so it is kept to one: the ray words a and b.  Planes and big spheres come
                         // from LDS; whether the ray re-hits the triangle it starts on was decided by k_shade.
-                        float4 A = q.a[ray], B;
+                        float4 A = ld_stream(&q.a[ray]), B;
                         if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                             B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
                             A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], A.x);
                         } else {
-                            B = q.b[ray];
+                            B = ld_stream(&q.b[ray]);
                         }
                         src = __float_as_uint(B.z);
                         if (src < SRC_SPECIAL) src &= ~(SRC_E_BIT | SRC_D_BIT);   // (k_shade's business: the ray carries its f64 origin / direction)
                         if (src == SRC_INVALID) {
-                            hits[ray] = make_float2(-1.f, __uint_as_float(HIT_INVALID));   // padding slot
+                            st_stream(&hits[ray], make_float2(-1.f, __uint_as_float(HIT_INVALID)));   // padding slot
                         } else if ((src >> 30) == 1u) {
                             // the ray re-hits the triangle it starts on at t ~ 1e-16 (k_shade's verdict, see tri_hit_ref):
                             // nothing can be closer, no traversal
-                            hits[ray] = make_float2(__uint_as_float(HIT_MISS), __uint_as_float(src & SRC_PRIM_MASK));   // (self-hits exist in scenes with triangles only: first word = runner-up, none)
+                            st_stream(&hits[ray], make_float2(__uint_as_float(HIT_MISS), __uint_as_float(src & SRC_PRIM_MASK)));   // (self-hits exist in scenes with triangles only: first word = runner-up, none)
                             if (COUNT) cnt_self++;
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
@@ -664,7 +723,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 pcur = pend = 0;
                                 active = true;
                             } else {
-                                hits[ray] = make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code));
+                                st_stream(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
                             }
                         }
                     }
@@ -778,7 +837,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
             if (!do_node && leafm) {
                 asm volatile("; RTMARK leaf");
                 const float4* __restrict__ base = prims + 3 * (size_t)pcur;
-                const float4 L0 = base[0], L1 = base[1], L2 = base[2];
+                const float4 L0 = base[0], L1 = base[1], L2 = base[2];   // (cached: the same policy as the queues here costs 9 % (C5) / 23 % (C4) of the kernel)
                 if (COUNT) cnt_prims++;
                 const uint32_t pi = pcur;
                 const uint32_t gid = __float_as_uint(L2.y);
@@ -835,7 +894,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 asm volatile("; RTMARK control");
             }
             if (active && node == STACK_SENTINEL && pcur >= pend) {
-                hits[ray] = make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code));
+                st_stream(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
                 active = false;
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
@@ -1019,8 +1078,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA, nC = nA;
     float2 nH = make_float2(0.f, 0.f);
     auto load_round = [&](uint32_t j) {
-        nA = qi.a[j]; nH = hits[j];
-        if (!PRIMARY) { nB = qi.b[j]; nC = qi.c[j]; }
+        nA = ld_stream(&qi.a[j]); nH = ld_stream(&hits[j]);
+        if (!PRIMARY) { nB = ld_stream(&qi.b[j]); nC = ld_stream(&qi.c[j]); }
     };
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (RT_SHADE_PREFETCH && i < n) load_round(i);
@@ -1101,9 +1160,12 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             uint32_t sw = 0;
             auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
                 dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
-                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT);
+                // (a hit on a sphere does not read the carried words: its hit point and normal -- a square root, a division -- mix every
+                // bit of the ray anew, so a ray whose f32 origin and direction get random low bits there is statistically the
+                // reference's; 16 bytes less to read for nine rays in ten of C5.  RT_SPHERE_E = 1 reads them there too.)
+                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT) && (flat || RT_SPHERE_E);
                 uint4 E = make_uint4(0u, 0u, 0u, 0u);
-                if (carried) E = qi.e[my];
+                if (carried) E = ld_stream(&qi.e[my]);
                 if (PRIMARY) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
                 else if (carried) o64 = mkd(join64(o.x, E.x), join64(o.y, E.y), join64(o.z, E.z));
                 else o64 = dither64(o, dh);
@@ -1112,12 +1174,12 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
                     // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
                     // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
-                    const uint4 E0 = qi.e[my];
+                    const uint4 E0 = ld_stream(&qi.e[my]);
                     d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
                 } else {
                     const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
                     uint4 F = make_uint4(0u, 0u, HIT_MISS, 0u);
-                    if (exact_d || self_ray) F = qi.f[my];
+                    if (exact_d || self_ray) F = ld_stream(&qi.f[my]);
                     if (exact_d) d64 = mkd(join64(d.x, E.w), join64(d.y, F.x), join64(d.z, F.y));
                     else d64 = dither64(d, dh);
                     if (self_ray) near_tri = F.z;   // the coplanar partner of the triangle this ray re-hits (HIT_MISS: none), see leaves_src
@@ -1182,7 +1244,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         // operands (see tri_hit_ref).  The ray enters it as f64: the exact eye for a primary ray, the
                         // carried f64 origin for a ray that re-hits its triangle, dithered f32 values otherwise.
                         const double2* __restrict__ r64 = reinterpret_cast<const double2*>(rec + 1);
-                        const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
+                        const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (cached: streamed past the caches like the queues, C5 +3.5 %, C4 +9 % step time -- the re-hit test reads the record again)
                         d3 o64;
                         ray64(o64, true);
                         double t0, a, b;
@@ -1347,7 +1409,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             if (sc.n_lights == 0) {
                 // without lights a path contributes exactly once, when it ends: ONE plain 16-byte store per path, black included
                 // (k_raygen then need not clear the word: 16 bytes per path less)
-                if (!emit) radiance[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
+                if (!emit) st_stream(&radiance[pid], make_float4(rad.x, rad.y, rad.z, 0.f));
             } else if (has_rad) {
                 // shadow rays of one path end in different lanes / launches
                 float* r = reinterpret_cast<float*>(radiance + pid);
@@ -1410,11 +1472,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             if (emit) {
                 if (slot < capacity) {
                     const uint32_t src_out = src_next;
-                    qo.a[slot] = make_float4(p.x, p.y, p.z, ndir.x);
-                    qo.b[slot] = make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid));
-                    qo.c[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng));
-                    if (TRIS && has_p64) qo.e[slot] = make_uint4(p_lo.x, p_lo.y, p_lo.z, d_lo_x);
-                    if (TRIS && (dir_exact || (src_out >> 30) == 1u)) qo.f[slot] = make_uint4(d_lo_y, d_lo_z, other_next, 0u);
+                    st_stream(&qo.a[slot], make_float4(p.x, p.y, p.z, ndir.x));
+                    st_stream(&qo.b[slot], make_float4(ndir.y, ndir.z, __uint_as_float(src_out), __uint_as_float(pid)));
+                    st_stream(&qo.c[slot], make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng)));
+                    if (TRIS && has_p64) st_stream(&qo.e[slot], make_uint4(p_lo.x, p_lo.y, p_lo.z, d_lo_x));
+                    if (TRIS && (dir_exact || (src_out >> 30) == 1u)) st_stream(&qo.f[slot], make_uint4(d_lo_y, d_lo_z, other_next, 0u));
                 } else {
                     atomicAdd(&ctl[CTL_OVERFLOW], 1u);
                 }
@@ -1452,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_accumulate(DevScene sc, PassParams pp, 
     if (!slot_to_pixel(sc, pp, pl, x, row)) return;
     float r = 0.f, g = 0.f, b = 0.f;
     for (uint32_t s = 0; s < pp.n_samples; ++s) {
-        const float4 c = radiance[(size_t)s * pp.npix_pad + pl];
+        const float4 c = ld_stream(&radiance[(size_t)s * pp.npix_pad + pl]);
         r += c.x; g += c.y; b += c.z;
     }
     float* dst = accum + ((size_t)row * sc.width + x) * 3u;
