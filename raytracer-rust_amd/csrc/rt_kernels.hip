@@ -152,6 +152,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
     return x < sc.width && row < sc.height;
 }
 
+#ifndef RT_SHADE_PREFETCH_S
+#define RT_SHADE_PREFETCH_S 1   // the first word of the next round's shading record is gathered behind the slot claim (see k_shade)
+#endif
 #ifndef RT_SHADE_SORT
 #define RT_SHADE_SORT 0   // 1: the rays of a block round are sorted by hit class through LDS (measured: C5 +1.5 %, C4 +2.5 % step time; see k_shade)
 #endif
@@ -1081,6 +1084,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         nA = ld_stream(&qi.a[j]); nH = ld_stream(&hits[j]);
         if (!PRIMARY) { nB = ld_stream(&qi.b[j]); nC = ld_stream(&qi.c[j]); }
     };
+    // ... and the first word of the shading record of the next round's hit (normal / material / kind) right behind the claim, when
+    // the hit word has arrived: the material gather, which needs it, then starts at the top of the round beside the record's other
+    // words instead of one memory round trip later.
+    float4 nS = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nS_code = HIT_MISS;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (RT_SHADE_PREFETCH && i < n) load_round(i);
     for (; i < n_pad; i += stride) {   // block-uniform trip count
@@ -1235,7 +1243,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 } else {
                     // one 96-byte shading record per primitive
                     const float4* __restrict__ rec = sc.smeta + SMETA_WORDS * (size_t)code;
-                    const float4 S = rec[0];
+                    const float4 S = (RT_SHADE_PREFETCH_S && nS_code == code) ? nS : rec[0];
                     sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
                     if (TRIS && !(sw & SMETA_SPHERE)) {
@@ -1469,6 +1477,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         if (!last) {
             // (ordering the block's slots by the octant of the new direction was measured: no gain)
             const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
+            if (RT_SHADE_PREFETCH && RT_SHADE_PREFETCH_S) {
+                const uint32_t c = strip_hit(__float_as_uint(nH.y));
+                nS_code = ((uint64_t)i + stride < n && c < SRC_SPECIAL && !(c & HIT_PLANE_BIT)) ? c : HIT_MISS;
+                if (nS_code != HIT_MISS) nS = sc.smeta[SMETA_WORDS * (size_t)c];
+            }
             if (emit) {
                 if (slot < capacity) {
                     const uint32_t src_out = src_next;
