@@ -682,6 +682,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             pp.off_x = (float)p->sample_offset[0]; pp.off_y = (float)p->sample_offset[1];
             pp.seed_lo = (uint32_t)p->seed; pp.seed_hi = (uint32_t)(p->seed >> 32);
             // scenes without lights: every path stores its radiance exactly once (k_shade), no clear needed
+            pp.inv_npix_pad = 1.0 / (double)pp.npix_pad; pp.inv_tiles_x = 1.0 / (double)tiles_x;
             pp.clear_radiance = (sc.n_lights > 0 || hits_only || p->depth == 0) ? 1u : 0u;
             if (pp_out) *pp_out = pp;
             HIP_TRY(ctx, hipMemsetAsync(ws.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));

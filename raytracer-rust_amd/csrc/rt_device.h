@@ -138,6 +138,7 @@ struct PassParams {
     double step64;            // 1 / ssaa_n in f64 (anti_aliasing.rs:94)
     float off_x, off_y;
     uint32_t seed_lo, seed_hi;
+    double inv_npix_pad, inv_tiles_x;   // 1.0 / npix_pad, 1.0 / tiles_x (div_by; 1.0 / ssaa_n is step64)
     uint32_t clear_radiance;  // k_raygen zeroes the paths' radiance words: scenes with lights (shadow rays add to them), passes that shade nothing
 };
 

@@ -3,7 +3,7 @@
 gfx950 assembly of the shipped source and flags (hipcc -S).  The regions are delimited by the `; RTMARK <name>` comments
 the kernel emits through empty inline asm.
 
-  python tools/isa_histogram.py [--out profiles/r02_isa_closest_hit]   ->  <out>.txt (table) and <out>.json
+  python tools/isa_histogram.py [--out profiles/r03_isa_closest_hit]   ->  <out>.txt (table) and <out>.json
 
 Per region: instructions by class, in total and on the straight-line path (`always`: not skippable by a forward
 s_cbranch inside the region), and VALU pipe cycles: a wave64 VALU instruction occupies its SIMD-32 pipe for 2 cycles,
@@ -55,7 +55,7 @@ def classify(op):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_closest_hit"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_isa_closest_hit"))
     ap.add_argument("--kernel", default="k_closest_hitILb0ELb1E")   # <COUNT = false, TRIS = true>
     ap.add_argument("--keep-asm", default=None)
     args = ap.parse_args()
