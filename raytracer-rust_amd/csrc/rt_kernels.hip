@@ -86,6 +86,16 @@ __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
     *p = v;
 #endif
 }
+#ifndef RT_NT_HITS
+#define RT_NT_HITS 0   // hit records are written a few lanes at a time as rays finish: L2 combines them (cached: closest-hit -0.5 %)
+#endif
+#ifndef RT_NT_RAD
+#define RT_NT_RAD 1
+#endif
+__device__ __forceinline__ void st_stream(float2* p, float2 v);
+__device__ __forceinline__ void st_stream(float4* p, float4 v);
+__device__ __forceinline__ void st_hits(float2* p, float2 v) { if (RT_NT_HITS) st_stream(p, v); else *p = v; }
+__device__ __forceinline__ void st_rad(float4* p, float4 v) { if (RT_NT_RAD) st_stream(p, v); else *p = v; }
 __device__ __forceinline__ void st_stream(float2* p, float2 v) {
 #if RT_NT
     __builtin_nontemporal_store(v2f_{v.x, v.y}, reinterpret_cast<v2f_*>(p));
@@ -688,11 +698,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         src = __float_as_uint(B.z);
                         if (src < SRC_SPECIAL) src &= ~(SRC_E_BIT | SRC_D_BIT);   // (k_shade's business: the ray carries its f64 origin / direction)
                         if (src == SRC_INVALID) {
-                            st_stream(&hits[ray], make_float2(-1.f, __uint_as_float(HIT_INVALID)));   // padding slot
+                            st_hits(&hits[ray], make_float2(-1.f, __uint_as_float(HIT_INVALID)));   // padding slot
                         } else if ((src >> 30) == 1u) {
                             // the ray re-hits the triangle it starts on at t ~ 1e-16 (k_shade's verdict, see tri_hit_ref):
                             // nothing can be closer, no traversal
-                            st_stream(&hits[ray], make_float2(__uint_as_float(HIT_MISS), __uint_as_float(src & SRC_PRIM_MASK)));   // (self-hits exist in scenes with triangles only: first word = runner-up, none)
+                            st_hits(&hits[ray], make_float2(__uint_as_float(HIT_MISS), __uint_as_float(src & SRC_PRIM_MASK)));   // (self-hits exist in scenes with triangles only: first word = runner-up, none)
                             if (COUNT) cnt_self++;
                         } else {
                             o = mk(A.x, A.y, A.z); d = mk(A.w, B.x, B.y);
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 pcur = pend = 0;
                                 active = true;
                             } else {
-                                st_stream(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
+                                st_hits(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
                             }
                         }
                     }
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                 asm volatile("; RTMARK control");
             }
             if (active && node == STACK_SENTINEL && pcur >= pend) {
-                st_stream(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
+                st_hits(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
                 active = false;
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
@@ -1432,7 +1442,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             if (sc.n_lights == 0) {
                 // without lights a path contributes exactly once, when it ends: ONE plain 16-byte store per path, black included
                 // (k_raygen then need not clear the word: 16 bytes per path less)
-                if (!emit) st_stream(&radiance[pid], make_float4(rad.x, rad.y, rad.z, 0.f));
+                if (!emit) st_rad(&radiance[pid], make_float4(rad.x, rad.y, rad.z, 0.f));
             } else if (has_rad) {
                 // shadow rays of one path end in different lanes / launches
                 float* r = reinterpret_cast<float*>(radiance + pid);
