@@ -179,6 +179,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #ifndef RT_SPHERE_E
 #define RT_SPHERE_E 0
 #endif
+#ifndef RT_NEAR_F64
+#define RT_NEAR_F64 1
+#endif
 #ifndef RT_TIE_SHADE
 #define RT_TIE_SHADE 1    // 0: k_shade ignores the runner-up (measurements only)
 #endif
@@ -434,7 +437,13 @@ __device__ __forceinline__ f3 sphere_normal(const float4 r0, const float4 r1, f3
 // own f64 directions carry.  (The same sequence in f32 -- round 1 -- gave
 // 0.05 ... 0.95 where the reference has 0.3; it only happened to agree on scenes/cube, whose coordinates are exact.)
 #ifndef RT_FAST_DIV
-#define RT_FAST_DIV 1
+// 0: the reference's quotients are IEEE divisions.  1 (measured, off): three quotients by one divisor as one division and
+// x / m = q + (x - q m) r, q = x r, r = 1 / m (Markstein) -- the correctly rounded quotient for ordinary operands, no faster in
+// k_shade (which waits on memory), and WRONG where r overflows: a direction with an exact zero component enters the f64 sequences
+// with dither bits as a denormal ~1e-315, the determinants it scales are denormal too, their quotient is an ordinary number and
+// r = 1 / m is inf.  Axis-aligned scenes at exactly representable coordinates hit that case: 5 findings in 500 scenes of
+// tools/soak_objects.py (objects 7 ... 40 % too bright) until the divisions came back.
+#define RT_FAST_DIV 0
 #endif
 __device__ __forceinline__ double quot_ref(double x, double m, double r) {   // x / m, r = 1 / m (correctly rounded)
     const double q = x * r;
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             // (resolve_tie).  One slot: of several such candidates the last one tested stays.
                             if (t > 0x1p-17f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)))
                                 consider(tris, tie_k, best, t, pi, gid);   // the barycentrics are recomputed by k_shade where a texture needs them
-                            else if (tris)
+                            else if (tris && RT_NEAR_F64)
                                 best.aux = pi | AUX_NEAR_BIT;              // f32 cannot rank it: k_shade's f64 test decides (resolve_tie)
                         }
                     }

@@ -110,8 +110,9 @@ def load_library():
     L.rt_scene_upload_devices.argtypes = [C.POINTER(vp), u32, C.POINTER(SceneDesc)]
     L.rt_accum_reduce.restype = C.c_int
     L.rt_accum_reduce.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), u32, vp]
-    L.rt_accum_reduce_rccl.restype = C.c_int
-    L.rt_accum_reduce_rccl.argtypes = [C.POINTER(vp), C.POINTER(vp), u32]
+    if hasattr(L, "rt_accum_reduce_rccl") or not os.environ.get("RTAMD_LIB"):      # (an RTAMD_LIB build of an older revision may lack it: A/B runs only)
+        L.rt_accum_reduce_rccl.restype = C.c_int
+        L.rt_accum_reduce_rccl.argtypes = [C.POINTER(vp), C.POINTER(vp), u32]
     L.rt_render_image_devices.restype = C.c_int
     L.rt_render_image_devices.argtypes = [C.POINTER(vp), u32, C.POINTER(RenderParamsC), C.c_int, vp, vp]
     L.rt_get_stats.restype = C.c_int

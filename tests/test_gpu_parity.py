@@ -478,6 +478,24 @@ def test_a_box_face_in_the_plane_y_equals_zero(ctx):
     assert abs(got / want - 1.0) < 0.01, (got, want)
 
 
+def test_boxes_stacked_at_multiples_of_an_eighth(ctx):
+    """Scene 10033 of tools/soak_objects.py: a Lambertian box on a box (the faces in y = 1.25 coincide), a glass box, ground plane and
+    an emitting sphere, every coordinate a multiple of 1/8, the camera looking exactly along -z.  The per-object soak flagged its
+    first box at 1.40 of the oracle's radiance (z = +312) on the kernels that formed the reference's three quotients a = Ma / M,
+    b = Mb / M, t = -Mt / M with ONE division and two FMAs each (x / m = q + (x - q m) r, r = 1 / m): exact for ordinary operands,
+    but a direction with an exact zero component enters the f64 sequence with dither bits as a denormal, M is then denormal, r = inf
+    and the quotients NaN where the division gives ordinary numbers.  The quotients are IEEE divisions (RT_FAST_DIV = 0)."""
+    lam = lambda c: dict(type="Lambertian", albedo=c)
+    objs = [_mesh(_box([-1.125, 0.375, 0.375], [0.0, 1.25, 1.75]), lam([0.7552559979696203, 0.31609736893749824, 0.4499331690700699])),
+            _mesh(_box([-1.0, 1.25, 0.375], [-0.25, 1.625, 0.875]), lam([0.32203322900493814, 0.6620052466890284, 0.36084090994144863])),
+            _mesh(_box([-1.375, -0.25, -2.0], [-0.625, 1.0, -1.375]), dict(type="Dieletrics", tint=[0.9277299569434767, 0.9985869686072995, 0.9247613444281153], refraction_index=1.886)),
+            dict(type="Plane", center=[0.0, -0.25, 0.0], normal=[0.0, 1.0, 0.0], material=lam([0.6, 0.6, 0.6])),
+            dict(type="Sphere", center=[2.875, 3.625, 1.75], radius=0.625, material=dict(type="Emissive", color=[3.9736012557661393, 4.8643268841417795, 5.768922539878439]))]
+    cam = dict(eye=[0.0, 1.375, 6.0], look_at=[0.0, 1.375, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)
+    got, want = _mean_where(ctx, objs, [0.8368196684545302, 0.8460556376207935, 0.5736568618355395], cam, 48, 36, 3, lambda ids, img: ids == 0, 13, chan=slice(None))
+    assert abs(got / want - 1.0) < 0.02, (got, want)
+
+
 def _flip(verts):
     return verts.reshape(-1, 3, 3)[:, [0, 2, 1]].reshape(-1, 3)
 
