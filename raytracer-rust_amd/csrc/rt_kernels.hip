@@ -179,6 +179,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #ifndef RT_SPHERE_E
 #define RT_SPHERE_E 0
 #endif
+#ifndef RT_SPHERE_RANK32
+#define RT_SPHERE_RANK32 2   // scenes with triangles: spheres are ranked by an f32 test, k_shade forms the distance in f64 (1: those in BVH leaves only; 0: f64 discriminants)
+#endif
 #ifndef RT_NEAR_F64
 #define RT_NEAR_F64 1
 #endif
@@ -389,6 +392,32 @@ __device__ __forceinline__ float sphere_hit(const float4 r0, const float4 r1, f3
     if (!(q.disc >= 0.0)) return -1.f;
     const double sq = (double)sqrtf((float)q.disc);
     const float t1 = (float)(-q.hb - sq) * ia, t2 = (float)(-q.hb + sq) * ia;
+    if (t1 > 1e-5f) return t1;
+    if (t2 > 1e-5f) return t2;
+    return -1.f;
+}
+
+// The same test where the distance only RANKS candidates (scenes with triangles: k_shade forms every distance again with the
+// reference's f64 sequence, and two candidates within RT_TIE_EPS of each other are both handed to it): all in f32, with the
+// discriminant in the form that does not cancel, r^2 - |oc - (oc.d) d|^2 (the squared distance of the centre from the ray,
+// d a unit vector to f32 rounding) -- accurate to a few ulp of r^2 for the spheres of BVH leaves (radius below a quarter of the
+// scene diagonal; the big ones are tested in f64 at the refill).  22 VALU instructions instead of 112 with 31 in f64.
+__device__ __forceinline__ float sphere_rank32(const float4 r0, const float4 r1, f3 o, f3 d, bool from_self) {
+    const float cx = (float)__hiloint2double(__float_as_int(r0.y), __float_as_int(r0.x));
+    const float cy = (float)__hiloint2double(__float_as_int(r0.w), __float_as_int(r0.z));
+    const float cz = (float)__hiloint2double(__float_as_int(r1.y), __float_as_int(r1.x));
+    const float rad = (float)__hiloint2double(__float_as_int(r1.w), __float_as_int(r1.z));
+    const f3 oc = mk(o.x - cx, o.y - cy, o.z - cz);
+    const float hb = dot(oc, d);
+    if (from_self) {
+        const float t = -2.f * hb;
+        return t > 1e-5f ? t : -1.f;
+    }
+    const f3 l = mk(fmaf(-hb, d.x, oc.x), fmaf(-hb, d.y, oc.y), fmaf(-hb, d.z, oc.z));
+    const float disc = fmaf(rad, rad, -dot(l, l));
+    if (!(disc >= 0.f)) return -1.f;
+    const float sq = sqrtf(disc);
+    const float t1 = -hb - sq, t2 = -hb + sq;
     if (t1 > 1e-5f) return t1;
     if (t2 > 1e-5f) return t2;
     return -1.f;
@@ -744,7 +773,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 if (k < FIXED_SPHERES) { r0 = ld(fx + 2 * FIXED_PLANES + 3 * k); r1 = ld(fx + 2 * FIXED_PLANES + 3 * k + 1); r2 = ld(fx + 2 * FIXED_PLANES + 3 * k + 2); }
                                 else { r0 = prims[3 * pi]; r1 = prims[3 * pi + 1]; r2 = prims[3 * pi + 2]; }
                                 if (COUNT) cnt_prims++;
-                                const float t = sphere_hit64(r0, r1, o, d, src == pi);
+                                // (scenes with triangles: the distance only ranks, see sphere_rank32; for a radius-1000 sphere its f32
+                                // discriminant is good to ~3e-4 of a distance of 12, inside the band RT_TIE_EPS hands to k_shade)
+                                const float t = (TRIS && RT_SPHERE_RANK32 > 1) ? sphere_rank32(r0, r1, o, d, src == pi) : sphere_hit64(r0, r1, o, d, src == pi);
                                 if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
                             }
                             if (sc.n_leaf_prims) {
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     // they occupy 14 registers for the whole kernel, the difference between 6 and 8 waves/SIMD)
                     f3 o_ = o, d_ = d;
                     asm volatile("; RTMARK leaf_sphere" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
-                    const float t = sphere_hit(L0, L1, o_, d_, src == pi);
+                    const float t = (TRIS && RT_SPHERE_RANK32) ? sphere_rank32(L0, L1, o_, d_, src == pi) : sphere_hit(L0, L1, o_, d_, src == pi);
                     if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, gid);
                 }
                 asm volatile("; RTMARK leaf_end");
