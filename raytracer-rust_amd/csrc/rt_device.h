@@ -25,7 +25,17 @@ constexpr uint32_t SMETA_HAS_UV = 0x80000000u;
 constexpr uint32_t SMETA_SPHERE = 0x40000000u;
 constexpr uint32_t SMETA_FLAGS = SMETA_HAS_UV | SMETA_SPHERE;
 constexpr int32_t CHILD_EMPTY_CODE = (int32_t)0x80000000;   // == bvh.h CHILD_EMPTY
-constexpr uint32_t LDS_STACK = 16;            // traversal-stack entries per lane kept in LDS (4 KB per wave)
+// RT_POP_CULL: a traversal-stack entry carries the entry distance of its box beside the child code (8 bytes), and an entry whose
+// distance lies beyond the nearest hit found since it was pushed is dropped when it is popped -- without it every such entry
+// costs a whole node step (four loads, ~170 VALU) only to find that no child can be hit any more.
+#ifndef RT_POP_CULL
+#define RT_POP_CULL 0
+#endif
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK (RT_POP_CULL ? 9 : 16)
+#endif
+constexpr uint32_t LDS_STACK = RT_LDS_STACK;    // traversal-stack entries per lane kept in LDS (4 KB per wave without RT_POP_CULL, 4.5 KB with)
+constexpr uint32_t STACK_ENTRY_WORDS = RT_POP_CULL ? 2 : 1;
 constexpr uint32_t HIT_BLOCKS_PER_CU = 8;     // persistent closest-hit blocks (256 threads) per CU
 
 // control block (uint32 words, zeroed at the start of every pass)

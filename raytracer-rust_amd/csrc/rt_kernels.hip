@@ -633,13 +633,38 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                                     int it, uint32_t capacity) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
-    __shared__ uint32_t lds_stack[4 * LDS_STACK * 64];
     const uint32_t lane = lane_id();
+    Best best;
+#if RT_POP_CULL
+    // an entry = (child code, sort key of the node step that pushed it: the bits of the box's entry distance, slot in the low two);
+    // pop drops entries whose box begins beyond the nearest hit so far -- the very test the node step applies to a child
+    // (tn <= min(tf, best.t)), repeated with the best.t of now
+    typedef uint32_t ent_t __attribute__((ext_vector_type(2)));
+    __shared__ ent_t lds_stack[4 * LDS_STACK * 64];
+    typedef __attribute__((address_space(3))) ent_t lds_ent;
+    lds_ent* const stk = (lds_ent*)lds_stack + (threadIdx.x >> 6) * (LDS_STACK * 64u) + lane;
+    ent_t* const spill = reinterpret_cast<ent_t*>(sc.spill) + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * sc.spill_levels) * 64u + lane;
+    auto push = [&](uint32_t& sp_, uint32_t v, uint32_t key) {
+        if (sp_ < LDS_STACK) stk[sp_ * 64u] = ent_t{v, key};
+        else spill[(size_t)(sp_ - LDS_STACK) * 64u] = ent_t{v, key};
+        sp_++;
+    };
+    auto pop = [&](uint32_t& sp_) -> int32_t {
+        for (;;) {
+            sp_--;
+            ent_t v = stk[min(sp_, LDS_STACK - 1u) * 64u];
+            if (sp_ >= LDS_STACK) v = spill[(size_t)(sp_ - LDS_STACK) * 64u];
+            // (distances are non-negative floats: their bits order as integers; the sentinel's key is 0)
+            if ((v.y & ~3u) <= __float_as_uint(best.t)) return (int32_t)v.x;
+        }
+    };
+#else
+    __shared__ uint32_t lds_stack[4 * LDS_STACK * 64];
     // address-space-qualified so that stack accesses stay ds_read/ds_write (never flat)
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* const stk = (lds_u32*)lds_stack + (threadIdx.x >> 6) * (LDS_STACK * 64u) + lane;
     uint32_t* const spill = sc.spill + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * sc.spill_levels) * 64u + lane;
-    auto push = [&](uint32_t& sp_, uint32_t v) {
+    auto push = [&](uint32_t& sp_, uint32_t v, uint32_t) {
         if (sp_ < LDS_STACK) stk[sp_ * 64u] = v;
         else spill[(size_t)(sp_ - LDS_STACK) * 64u] = v;
         sp_++;
@@ -652,6 +677,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
         if (sp_ >= LDS_STACK) v = spill[(size_t)(sp_ - LDS_STACK) * 64u];
         return (int32_t)v;
     };
+#endif
     // A launch is sized for the most rays the iteration can have (the host does not wait for the count).  Blocks the
     // actual queue has no ray for leave at once: every wave that stays probes all fetch segments before it gives up, and
     // with thousands of idle waves those atomics -- not the few rays -- set the time of a small launch (the late
@@ -692,7 +718,6 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     int32_t node = STACK_SENTINEL;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     float idx = 0.f, idy = 0.f, idz = 0.f;
-    Best best;
     constexpr bool tris = TRIS;
     constexpr float tie_k = TRIS ? 1.f + 2.f * RT_TIE_EPS : 1.f;
     best.t = 0.f; best.code = HIT_MISS; best.aux = HIT_MISS;
@@ -785,7 +810,11 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 idx = __builtin_amdgcn_rcpf(fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
                                 idy = __builtin_amdgcn_rcpf(fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
                                 idz = __builtin_amdgcn_rcpf(fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+#if RT_POP_CULL
+                                stk[0] = ent_t{(uint32_t)STACK_SENTINEL, 0u};
+#else
                                 stk[0] = (uint32_t)STACK_SENTINEL;
+#endif
                                 sp = 1;
                                 node = 0;            // root is always an inner node
                                 pcur = pend = 0;
@@ -887,9 +916,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     nxt = pop(sp);
                 } else {
                     // nearest child next; the others wait on the stack, nearest of them on top
-                    if (nhit > 3u) push(sp, (uint32_t)cc[3]);
-                    if (nhit > 2u) push(sp, (uint32_t)cc[2]);
-                    if (nhit > 1u) push(sp, (uint32_t)cc[1]);
+                    if (nhit > 3u) push(sp, (uint32_t)cc[3], key[3]);
+                    if (nhit > 2u) push(sp, (uint32_t)cc[2], key[2]);
+                    if (nhit > 1u) push(sp, (uint32_t)cc[1], key[1]);
                     nxt = cc[0];
                 }
                 if (nxt < 0 && !leafm) {
