@@ -50,6 +50,7 @@ struct rt_context {
     DevScene sc{};
     std::vector<void*> scene_allocs;
     int bvh_builder = 0;      // 0: host binned SAH (bvh.cpp), 1: GPU LBVH (bvh_gpu.hip)
+    bool tile_entry = true;   // primary rays enter the BVH at their tile's entry points (k_tile_entry); RTAMD_TILE_ENTRY=0: at the root (A/B, tests)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_prims = 0;
     double bvh_build_ms = 0;
 
@@ -196,6 +197,7 @@ int rt_context_create(int device_id, rt_context** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
     rt_context* ctx = new rt_context();
+    if (const char* e = getenv("RTAMD_TILE_ENTRY")) ctx->tile_entry = atoi(e) != 0;
     ctx->device = device_id;
     ctx->cfg.n_cu = (uint32_t)prop.multiProcessorCount;
     DeviceGuard g(device_id);
@@ -687,6 +689,13 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             if (pp_out) *pp_out = pp;
             HIP_TRY(ctx, hipMemsetAsync(ws.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
             launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
+            // entry points of the tiles' primary rays into the BVH (k_tile_entry): one int4 per tile of the pass, kept in the first
+            // words of queue 1's word f, which nothing touches before k_shade of iteration 0 writes the rays of iteration 1
+            TileEntry entry{nullptr, pp.npix_pad, pp.inv_npix_pad};
+            if (ctx->tile_entry && sc.n_leaf_prims && (hits_only || p->depth > 0)) {
+                entry.table = reinterpret_cast<const int4*>(ws.q[1].f);
+                launch_tile_entry(sc, pp, reinterpret_cast<int4*>(ws.q[1].f), st);
+            }
             {   // primary rays = pixels of the pass's tiles that lie inside the image
                 uint64_t px = 0;
                 for (uint32_t lt = lt0; lt < lt0 + nt; ++lt) {
@@ -712,7 +721,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                     }
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].first, st));
                 }
-                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, st);
+                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, it == 0 ? entry : TileEntry{nullptr, 0u, 0.0}, st);
                 if (timing) {
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].second, st));
                     ctx->events_used++;

@@ -135,6 +135,15 @@ struct DevScene {
     uint32_t spill_levels;    // max(0, stack_depth - LDS_STACK)
 };
 
+// Entry points of the primary rays of an 8x8 pixel tile into the BVH (k_tile_entry): up to four child codes (inner node index,
+// leaf code, CHILD_EMPTY_CODE = unused), nearest first, such that no ray of the tile can hit anything of the BVH outside their
+// subtrees.  table == nullptr: every ray starts at the root.
+struct TileEntry {
+    const int4* table;        // one entry per local tile of the pass
+    uint32_t npix_pad;        // PassParams::npix_pad, inv_npix_pad: path slot -> local tile
+    double inv_npix_pad;
+};
+
 struct PassParams {
     uint32_t n_paths;         // (number of local tiles in the pass) * 64 * n_samples
     uint32_t npix_pad;        // (number of local tiles in the pass) * 64

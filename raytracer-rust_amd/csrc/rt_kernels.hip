@@ -630,7 +630,7 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 
 template <bool COUNT, bool TRIS>   // TRIS: the scene has triangles (what Best::aux holds, see consider)
 __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float2* __restrict__ hits, uint32_t* __restrict__ ctl,
-                                                    int it, uint32_t capacity) {
+                                                    int it, uint32_t capacity, TileEntry entry) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
     const uint32_t lane = lane_id();
@@ -752,6 +752,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         // lanes wait, so it is kept to one: the ray words a and b.  Planes and big spheres come
                         // from LDS; whether the ray re-hits the triangle it starts on was decided by k_shade.
                         float4 A = ld_stream(&q.a[ray]), B;
+                        // where the ray enters the BVH: the root, or for a primary ray the entry points of its 8x8 tile (k_tile_entry)
+                        int4 F = make_int4(0, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
+                        if (it == 0 && entry.table) F = entry.table[(ray - div_by(ray, entry.inv_npix_pad) * entry.npix_pad) >> 6];
                         if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                             B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
                             A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], A.x);
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 const float t = (TRIS && RT_SPHERE_RANK32 > 1) ? sphere_rank32(r0, r1, o, d, src == pi) : sphere_hit64(r0, r1, o, d, src == pi);
                                 if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
                             }
-                            if (sc.n_leaf_prims) {
+                            if (sc.n_leaf_prims && F.x != CHILD_EMPTY_CODE) {
                                 const float ooeps = 0x1p-80f;
                                 // (v_rcp_f32, 1 ulp: the node test's rounding bound has room for it, see there;
                                 // three IEEE divisions were 30 instructions per refill)
@@ -816,8 +819,17 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 stk[0] = (uint32_t)STACK_SENTINEL;
 #endif
                                 sp = 1;
-                                node = 0;            // root is always an inner node
+                                if (F.w != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.w, 0u);
+                                if (F.z != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.z, 0u);
+                                if (F.y != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.y, 0u);
+                                node = F.x;          // (the root is always an inner node; a tile's entry point may be a leaf)
                                 pcur = pend = 0;
+                                if (node < 0) {
+                                    const uint32_t code = (uint32_t)~node;
+                                    pcur = code >> 3;
+                                    pend = pcur + (code & 7u) + 1u;
+                                    node = pop(sp);
+                                }
                                 active = true;
                             } else {
                                 st_hits(&hits[ray], make_float2(tris ? __uint_as_float(best.aux) : best.t, __uint_as_float(best.code)));
@@ -1020,6 +1032,147 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
             atomicAdd(st64 + 6, (unsigned long long)cl);
         }
     }
+}
+
+// ---------------------------------------------------------------- entry points of the primary rays
+// The 64 primary rays of a wave are the samples of one 8x8 pixel tile: a thin pyramid from the eye (2.6 mrad wide at 1080p,
+// fovy 20).  Walking the top of the BVH once per TILE instead of once per ray: one thread per tile descends from the root with a
+// conservative pyramid / box test and keeps a frontier of at most four children (inner nodes or leaves) outside whose subtrees no
+// ray of the tile can hit anything; a node of the frontier is replaced by those of its children the pyramid reaches while the
+// frontier still fits.  The rays of the tile then start their own traversal at the frontier (k_closest_hit, iteration 0) instead
+// of at the root, and a tile whose pyramid reaches nothing (sky, ground beyond the last sphere) needs no traversal at all.
+// The test: a box is cut off if it lies wholly on the outer side of one of the pyramid's four side planes (all through the eye),
+// or farther from the eye than the farthest point at which any ray of the tile can still find a hit -- known when all four
+// corner rays hit the same plane or the same big sphere (the things every ray tests outside the BVH; both are convex, so every
+// ray between the corners hits them too, nearer than the farthest corner hit).  All in f64 on the exact child boxes (p + q 2^e),
+// with the tile widened by RT_ENTRY_PAD pixels on every side: far more than the f32 rounding of a ray direction (6e-8) or the
+// slack of the f32 primitive tests, so the frontier never loses a hit the per-ray traversal from the root would find.
+#ifndef RT_ENTRY_PAD
+#define RT_ENTRY_PAD 0.05
+#endif
+__global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, int4* __restrict__ table) {
+    const uint32_t tl = blockIdx.x * blockDim.x + threadIdx.x;   // local tile of the pass
+    if (tl >= (pp.npix_pad >> 6)) return;
+    const int32_t EMPTY = CHILD_EMPTY_CODE;
+    const uint64_t gt = (uint64_t)(pp.ltile_begin + tl) * pp.tile_count + pp.tile_index;
+    if (gt >= (uint64_t)pp.tiles_x * pp.tiles_y || sc.n_leaf_prims == 0) { table[tl] = make_int4(EMPTY, EMPTY, EMPTY, EMPTY); return; }
+    const uint32_t ty = (uint32_t)(gt / pp.tiles_x), tx = (uint32_t)(gt - (uint64_t)ty * pp.tiles_x);
+    const uint32_t x_lo = tx * 8u, x_hi = min(x_lo + 8u, sc.width), r_lo = ty * 8u, r_hi = min(r_lo + 8u, sc.height);
+    // sample positions of the tile (primary_ray): px = x + off_x + [0, 1], py = (height - 1 - row) + off_y + [0, 1]
+    const double pxl = (double)x_lo + (double)pp.off_x - RT_ENTRY_PAD, pxh = (double)x_hi + (double)pp.off_x + RT_ENTRY_PAD;
+    const double pyl = (double)(sc.height - r_hi) + (double)pp.off_y - RT_ENTRY_PAD, pyh = (double)(sc.height - r_lo) + (double)pp.off_y + RT_ENTRY_PAD;
+    const d3 eye = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
+    auto dir = [&](double px, double py) {
+        return mkd(sc.ll[0] + sc.hz[0] * px + sc.vt[0] * py - eye.x, sc.ll[1] + sc.hz[1] * px + sc.vt[1] * py - eye.y, sc.ll[2] + sc.hz[2] * px + sc.vt[2] * py - eye.z);
+    };
+    auto dotd = [](d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    auto crossd = [](d3 a, d3 b) { return mkd(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); };
+    d3 c[4] = {dir(pxl, pyl), dir(pxh, pyl), dir(pxh, pyh), dir(pxl, pyh)};
+    // inward normals of the four side planes (edge k, k+1; the corner opposite decides the orientation)
+    d3 pn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d3 n = crossd(c[k], c[(k + 1) & 3]);
+        if (dotd(n, c[(k + 2) & 3]) < 0.0) n = mkd(-n.x, -n.y, -n.z);
+        pn[k] = n;
+    }
+    // the farthest distance at which a ray of the tile can still find its closest hit
+    double tmax = __builtin_inf();
+    {
+        d3 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double l = sqrt(dotd(c[k], c[k]));
+            u[k] = l > 0.0 ? mkd(c[k].x / l, c[k].y / l, c[k].z / l) : c[k];
+        }
+        for (uint32_t p = 0; p < sc.n_planes; ++p) {                      // intersections.rs:82-104
+            const double* __restrict__ P = sc.planes64 + 6 * (size_t)p;
+            const d3 pc = mkd(P[0] - eye.x, P[1] - eye.y, P[2] - eye.z), n = mkd(P[3], P[4], P[5]);
+            const double num = dotd(pc, n);
+            double far = 0.0;
+            bool all = true;
+            const double dn0 = dotd(n, u[0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dn = dotd(n, u[k]);
+                const double t = num / dn;
+                all = all && fabs(dn) > 1e-4 && (dn > 0.0) == (dn0 > 0.0) && t > 1e-3;
+                far = fmax(far, t);
+            }
+            if (all) tmax = fmin(tmax, far);
+        }
+        for (uint32_t pi = sc.n_leaf_prims; pi < sc.n_prims; ++pi) {      // big spheres, intersections.rs:40-80
+            const double2* __restrict__ S = reinterpret_cast<const double2*>(sc.prims + 3 * (size_t)pi);
+            const double2 s0 = S[0], s1 = S[1];
+            const d3 oc = mkd(eye.x - s0.x, eye.y - s0.y, eye.z - s1.x);
+            const double r2 = s1.y * s1.y, cc = dotd(oc, oc) - r2;
+            if (!(cc > 1e-6 * r2)) continue;                              // the eye is inside or on the sphere: no bound from it
+            double far = 0.0;
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double hb = dotd(oc, u[k]), disc = hb * hb - cc;
+                const double t = -hb - sqrt(fmax(disc, 0.0));
+                all = all && disc > 0.0 && t > 1e-3;
+                far = fmax(far, t);
+            }
+            if (all) tmax = fmin(tmax, far);
+        }
+    }
+    const double tmax2 = tmax < 1e150 ? tmax * tmax * (1.0 + 4e-3) : __builtin_inf();
+    // frontier: codes, squared distance of the box from the eye (the order in which the rays will try them), "not to be expanded"
+    int32_t code[4] = {0, EMPTY, EMPTY, EMPTY};
+    double key[4] = {0.0, 0.0, 0.0, 0.0};
+    bool fin[4] = {false, false, false, false};
+    int n = 1;
+    for (int iter = 0; iter < 96; ++iter) {
+        int i = -1;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) if (k < n && code[k] >= 0 && !fin[k]) i = k;
+        if (i < 0) break;
+        const float4* __restrict__ base = sc.nodes + 4 * (size_t)code[i];
+        const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
+        const double sx = (double)fabsf(__uint_as_float(__float_as_uint(L0.w) << 23)), sy = (double)L3.z, sz = (double)L3.w;
+        const uint32_t ql[3] = {__float_as_uint(L2.x), __float_as_uint(L2.y), __float_as_uint(L2.z)};
+        const uint32_t qh[3] = {__float_as_uint(L2.w), __float_as_uint(L3.x), __float_as_uint(L3.y)};
+        const int32_t ch[4] = {__float_as_int(L1.x), __float_as_int(L1.y), __float_as_int(L1.z), __float_as_int(L1.w)};
+        int32_t hc[4];
+        double hk[4];
+        int nh = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ch[k] == EMPTY) continue;
+            const d3 lo = mkd((double)L0.x + (double)((ql[0] >> (8 * k)) & 0xFFu) * sx, (double)L0.y + (double)((ql[1] >> (8 * k)) & 0xFFu) * sy,
+                              (double)L0.z + (double)((ql[2] >> (8 * k)) & 0xFFu) * sz);
+            const d3 hi = mkd((double)L0.x + (double)((qh[0] >> (8 * k)) & 0xFFu) * sx, (double)L0.y + (double)((qh[1] >> (8 * k)) & 0xFFu) * sy,
+                              (double)L0.z + (double)((qh[2] >> (8 * k)) & 0xFFu) * sz);
+            bool out = false;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const d3 nn = pn[pl];
+                const d3 v = mkd((nn.x >= 0.0 ? hi.x : lo.x) - eye.x, (nn.y >= 0.0 ? hi.y : lo.y) - eye.y, (nn.z >= 0.0 ? hi.z : lo.z) - eye.z);
+                out = out || dotd(nn, v) < 0.0;
+            }
+            const double ddx = fmax(fmax(lo.x - eye.x, eye.x - hi.x), 0.0), ddy = fmax(fmax(lo.y - eye.y, eye.y - hi.y), 0.0),
+                         ddz = fmax(fmax(lo.z - eye.z, eye.z - hi.z), 0.0);
+            const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            out = out || d2 > tmax2;
+            if (!out) { hc[nh] = ch[k]; hk[nh] = d2; nh++; }
+        }
+        if (n - 1 + nh <= 4) {
+            // the node gives way to the children the pyramid reaches
+            for (int k = i; k + 1 < n; ++k) { code[k] = code[k + 1]; key[k] = key[k + 1]; fin[k] = fin[k + 1]; }
+            n--;
+            for (int k = 0; k < nh; ++k) { code[n] = hc[k]; key[n] = hk[k]; fin[n] = false; n++; }
+        } else {
+            fin[i] = true;
+        }
+    }
+    // nearest first
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (key[b] < key[a]) { const double tk = key[a]; key[a] = key[b]; key[b] = tk; const int32_t tc = code[a]; code[a] = code[b]; code[b] = tc; }
+    table[tl] = make_int4(n > 0 ? code[0] : EMPTY, n > 1 ? code[1] : EMPTY, n > 2 ? code[2] : EMPTY, n > 3 ? code[3] : EMPTY);
 }
 
 // ---------------------------------------------------------------- shading
@@ -1751,19 +1904,22 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
     uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
 }
+void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hipStream_t st) {
+    hipLaunchKernelGGL(k_tile_entry, dim3(cdiv(pp.npix_pad >> 6, 64)), dim3(64), 0, st, sc, pp, table);
+}
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
-                        uint32_t max_rays, bool counters, hipStream_t st) {
+                        uint32_t max_rays, bool counters, TileEntry entry, hipStream_t st) {
     uint32_t per_cu = HIT_BLOCKS_PER_CU;
     if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
     const size_t lds = 0;
     const dim3 g(blocks), b(256);
     if (sc.n_tris) {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
-        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
+        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
     } else {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
-        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity);
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
+        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
     }
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,

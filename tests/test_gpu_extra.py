@@ -309,3 +309,48 @@ def test_c_abi_host_code_under_asan():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
     assert "all checks passed" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+def test_tile_entry_points_change_nothing():
+    """k_tile_entry: the primary rays of an 8x8 tile start their traversal at the tile's entry points into the BVH instead of
+    at the root.  The entry points must lose no hit: ids, t and normal of every primary ray, and whole renders of scenes without
+    lights (deterministic per seed), are identical with the entry points switched off (RTAMD_TILE_ENTRY=0: every ray starts at the
+    root) -- on the reference's cube, spheres behind and beside each other (C3), the torus seen through its hole with the plane
+    behind it (C4) and both together (C5), at sub-pixel offsets at the edges of the pixels, odd image sizes and a tile split."""
+    def contexts():
+        os.environ["RTAMD_TILE_ENTRY"] = "0"
+        try:
+            off = rt.Context(0)
+        finally:
+            del os.environ["RTAMD_TILE_ENTRY"]
+        return off, rt.Context(0)
+
+    off, on = contexts()
+    try:
+        cube = rt.Scene.load(os.path.join(GOLDEN, "scenes", "cube", "cube.yaml"), base_dir=GOLDEN)
+        scenes = [("cube", cube)]
+        for name, sc in (("c3", scenegen.scene_c3(323, 181)), ("c4", scenegen.scene_c4(387, 213, 120, 60)), ("c5", scenegen.scene_c5(645, 363, 200, 100))):
+            scenes.append((name, rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"])))
+        for name, scene in scenes:
+            off.upload(scene)
+            on.upload(scene)
+            for dx, dy in ((0.0, 0.0), (0.5, 0.5), (0.999, 0.001), (0.001, 0.999)):
+                a, b = off.primary_hits(dx, dy), on.primary_hits(dx, dy)
+                for k in ("object_id", "triangle_id", "t", "normal"):
+                    assert np.array_equal(a[k], b[k]), "%s: %s differs at offset (%g, %g) in %d pixels" % (name, k, dx, dy, (a[k] != b[k]).sum())
+            if name == "cube":
+                continue          # (two lights: shadow rays of one path add up in an order that is not fixed)
+            for kw in (dict(), dict(tile_index=1, tile_count=3)):
+                p = rt.RenderParams("jitter:3", depth=4, seed=77, **kw)
+                acc_a, _ = off.render_image(p)
+                acc_b, _ = on.render_image(p)
+                assert np.array_equal(acc_a, acc_b), "%s: renders differ in %d values" % (name, (acc_a != acc_b).sum())
+        # what the entry points save: node visits of the primary rays
+        on.stats_reset(); off.stats_reset()
+        p = rt.RenderParams("jitter:2", depth=1, seed=5, counters=True)
+        off.render_image(p); on.render_image(p)
+        n_off, n_on = off.stats()["nodes_visited"], on.stats()["nodes_visited"]
+        print("nodes visited by the primary rays of the last scene: %d at the root, %d at the tiles' entry points" % (n_off, n_on))
+        assert n_on < n_off
+    finally:
+        off.close(); on.close()
