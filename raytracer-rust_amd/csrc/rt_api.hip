@@ -50,6 +50,7 @@ struct rt_context {
     DevScene sc{};
     std::vector<void*> scene_allocs;
     int bvh_builder = 0;      // 0: host binned SAH (bvh.cpp), 1: GPU LBVH (bvh_gpu.hip)
+    bool any_hit_last = true; // the paths' last rays stop at their first hit in scenes without emitters; RTAMD_ANY_HIT=0 (read at rt_context_create, applied at scene upload): closest hit and full shading as for every ray (A/B, tests)
     bool tile_entry = true;   // primary rays enter the BVH at their tile's entry points (k_tile_entry); RTAMD_TILE_ENTRY=0: at the root (A/B, tests)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_prims = 0;
     double bvh_build_ms = 0;
@@ -198,6 +199,7 @@ int rt_context_create(int device_id, rt_context** out) {
         return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
     rt_context* ctx = new rt_context();
     if (const char* e = getenv("RTAMD_TILE_ENTRY")) ctx->tile_entry = atoi(e) != 0;
+    if (const char* e = getenv("RTAMD_ANY_HIT")) ctx->any_hit_last = atoi(e) != 0;
     ctx->device = device_id;
     ctx->cfg.n_cu = (uint32_t)prop.multiProcessorCount;
     DeviceGuard g(device_id);
@@ -260,6 +262,7 @@ struct FlatScene {
     float bg[3], eye[3];
     double eye64[3], lle[3], hz[3], vt[3], ll[3];
     uint32_t width = 0, height = 0, stack_depth = 2, bvh_depth = 0;
+    bool no_emitters = false;   // no Emissive and no Texture material (DevScene::no_emitters)
     double bvh_build_ms = 0;
 };
 
@@ -457,11 +460,13 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
     }
     std::vector<float4>& mats = f.mats;
     mats.assign((size_t)d->n_materials * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    f.no_emitters = d->n_lights == 0;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         mats[2 * i] = make_float4((float)d->mat_rgb[3 * i], (float)d->mat_rgb[3 * i + 1], (float)d->mat_rgb[3 * i + 2], (float)d->mat_param[i]);
         f.mat_param64.push_back(d->mat_param[i]);
         int32_t w[4] = {d->mat_type[i], d->mat_texture ? d->mat_texture[i] : -1, 0, 0};
         std::memcpy(&mats[2 * i + 1], w, 16);
+        if (d->mat_type[i] == RT_MAT_EMISSIVE || d->mat_type[i] == RT_MAT_TEXTURE) f.no_emitters = false;
     }
     std::vector<int4>& textures = f.textures;
     std::vector<uchar4>& texels = f.texels;
@@ -520,6 +525,7 @@ static int upload_flat(rt_context* ctx, const FlatScene& f) {
     sc.n_planes = f.n_planes;
     sc.n_tris = f.n_tris;
     sc.n_lights = f.n_lights;
+    sc.no_emitters = f.no_emitters && ctx->any_hit_last ? 1u : 0u;
     for (int k = 0; k < 3; ++k) { sc.bg[k] = f.bg[k]; sc.eye[k] = f.eye[k]; sc.eye64[k] = f.eye64[k]; sc.lle[k] = f.lle[k]; sc.ll[k] = f.ll[k]; sc.hz[k] = f.hz[k]; sc.vt[k] = f.vt[k]; }
     sc.width = f.width; sc.height = f.height;
     sc.stack_depth = f.stack_depth;
@@ -721,15 +727,17 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                     }
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].first, st));
                 }
-                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, it == 0 ? entry : TileEntry{nullptr, 0u, 0.0}, st);
+                // 0: a bounce before the last; 1: last bounce or a shadow generation, shadow rays go to the next
+                // generation; 2: the last generation this call runs (max_shadow_generations): nothing is emitted
+                const int last = it + 1 < depth ? 0 : (it + 1 < iters ? 1 : 2);
+                // the paths' last rays in a scene without emitters only ask WHETHER they hit (see k_closest_hit)
+                const bool any_hit = !hits_only && last != 0 && sc.no_emitters;
+                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, it == 0 ? entry : TileEntry{nullptr, 0u, 0.0}, any_hit, st);
                 if (timing) {
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].second, st));
                     ctx->events_used++;
                 }
                 if (hits_only) break;
-                // 0: a bounce before the last; 1: last bounce or a shadow generation, shadow rays go to the next
-                // generation; 2: the last generation this call runs (max_shadow_generations): nothing is emitted
-                const int last = it + 1 < depth ? 0 : (it + 1 < iters ? 1 : 2);
                 launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, st);
             }
             if (!hits_only) launch_accumulate(sc, pp, ws.radiance, accum_dev, st);

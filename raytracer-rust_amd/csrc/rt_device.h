@@ -122,6 +122,7 @@ struct DevScene {
     const uchar4* texels;
     const float4* lights;     // xyz of sample_points[0]
     uint32_t n_lights;
+    uint32_t no_emitters;     // no Emissive and no Texture material (whose back face emits): a path's last ray contributes the background or nothing
     float bg[3];
     float eye[3];
     double eye64[3];          // the reference's own f64 eye: origin of the primary rays in k_shade's f64 hit-point arithmetic

@@ -14,7 +14,7 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
                    uint32_t capacity, hipStream_t st);
 void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hipStream_t st);
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
-                        uint32_t max_rays, bool counters, TileEntry entry, hipStream_t st);
+                        uint32_t max_rays, bool counters, TileEntry entry, bool any_hit, hipStream_t st);
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
                   uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st);
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st);

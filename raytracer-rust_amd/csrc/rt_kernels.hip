@@ -604,6 +604,15 @@ __device__ __forceinline__ double join64(float hi, uint32_t lo) {
 #define RT_DIR_REF64 1   // scenes with triangles: mirror and dielectric bounces off triangles and planes in f64, their directions carried exactly (RayQueue::f); 2: off spheres too
 #endif
 constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal stack: "ray finished"
+#ifndef RT_ENTRY_K
+#define RT_ENTRY_K 4     // entry points per tile (k_tile_entry): 4 or 8
+#endif
+#ifndef RT_ENTRY_SUB
+#define RT_ENTRY_SUB 1   // entry points per SUB x SUB part of a tile (1: the 8x8 tile, 2: its 4x4 quarters, 4: 2x2 pixels)
+#endif
+#ifndef RT_ENTRY_MAXH
+#define RT_ENTRY_MAXH 4  // a frontier node gives way to its children only if the tile's pyramid reaches at most this many of them
+#endif
 #ifndef RT_REFILL
 #define RT_REFILL 32
 #endif
@@ -628,9 +637,13 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 #define RT_HIT_MIN_WAVES 8   // waves per SIMD the register allocator must allow: 64 VGPRs, no spills (6 waves/80 VGPRs: 4.57 ms per launch, 7: 4.38, 8: 4.30)
 #endif
 
+// any_hit: the launch serves the LAST rays of the paths of a scene without emitters (no Emissive or Texture material, hence no
+// lights): such a ray contributes the background if it escapes and nothing otherwise (raytrace.rs:52-54,95: whatever it hits
+// scatters into a ray that returns black), so WHICH surface it hits first does not matter and its traversal ends at the first
+// hit it finds.  A candidate at t ~ 0 that f32 cannot decide (AUX_NEAR_BIT) is no such hit: it still goes to k_shade's f64 test.
 template <bool COUNT, bool TRIS>   // TRIS: the scene has triangles (what Best::aux holds, see consider)
 __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float2* __restrict__ hits, uint32_t* __restrict__ ctl,
-                                                    int it, uint32_t capacity, TileEntry entry) {
+                                                    int it, uint32_t capacity, TileEntry entry, int any_hit) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
     const uint32_t lane = lane_id();
@@ -754,7 +767,20 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         float4 A = ld_stream(&q.a[ray]), B;
                         // where the ray enters the BVH: the root, or for a primary ray the entry points of its 8x8 tile (k_tile_entry)
                         int4 F = make_int4(0, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
-                        if (it == 0 && entry.table) F = entry.table[(ray - div_by(ray, entry.inv_npix_pad) * entry.npix_pad) >> 6];
+                        auto entry_index = [&]() -> size_t {
+                            const uint32_t pl = ray - div_by(ray, entry.inv_npix_pad) * entry.npix_pad;   // tile * 64 + (row in tile) * 8 + column
+                            constexpr uint32_t S = RT_ENTRY_SUB, W = 8u / S;
+                            return (size_t)(pl >> 6) * (S * S) + (((pl >> 3) & 7u) / W) * S + (pl & 7u) / W;
+                        };
+#if RT_ENTRY_K > 4
+                        int4 F1 = make_int4(CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
+                        if (it == 0 && entry.table) {
+                            const int4* __restrict__ fe = entry.table + 2 * entry_index();
+                            F = fe[0]; F1 = fe[1];
+                        }
+#else
+                        if (it == 0 && entry.table) F = entry.table[entry_index()];
+#endif
                         if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                             B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
                             A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], A.x);
@@ -806,7 +832,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 const float t = (TRIS && RT_SPHERE_RANK32 > 1) ? sphere_rank32(r0, r1, o, d, src == pi) : sphere_hit64(r0, r1, o, d, src == pi);
                                 if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
                             }
-                            if (sc.n_leaf_prims && F.x != CHILD_EMPTY_CODE) {
+                            if (sc.n_leaf_prims && F.x != CHILD_EMPTY_CODE && !(any_hit && best.code != HIT_MISS)) {
                                 const float ooeps = 0x1p-80f;
                                 // (v_rcp_f32, 1 ulp: the node test's rounding bound has room for it, see there;
                                 // three IEEE divisions were 30 instructions per refill)
@@ -819,6 +845,12 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 stk[0] = (uint32_t)STACK_SENTINEL;
 #endif
                                 sp = 1;
+#if RT_ENTRY_K > 4
+                                if (F1.w != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.w, 0u);
+                                if (F1.z != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.z, 0u);
+                                if (F1.y != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.y, 0u);
+                                if (F1.x != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.x, 0u);
+#endif
                                 if (F.w != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.w, 0u);
                                 if (F.z != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.z, 0u);
                                 if (F.y != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.y, 0u);
@@ -992,6 +1024,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, gid);
                 }
                 asm volatile("; RTMARK leaf_end");
+                if (any_hit && best.code != HIT_MISS) { node = STACK_SENTINEL; pend = pcur; }   // a hit: that is all the path's last ray asks
                 pcur++;
                 if (pcur == pend && node < 0) {
                     // the leaf that was waiting moves in, the stack gives the next piece of work
@@ -1051,13 +1084,21 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
 #define RT_ENTRY_PAD 0.05
 #endif
 __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, int4* __restrict__ table) {
-    const uint32_t tl = blockIdx.x * blockDim.x + threadIdx.x;   // local tile of the pass
-    if (tl >= (pp.npix_pad >> 6)) return;
+    constexpr uint32_t S = RT_ENTRY_SUB, SW = 8u / S;
+    const uint32_t te = blockIdx.x * blockDim.x + threadIdx.x;   // (local tile of the pass, part of the tile)
+    if (te >= (pp.npix_pad >> 6) * (S * S)) return;
+    const uint32_t tl = te / (S * S), sub = te % (S * S);
     const int32_t EMPTY = CHILD_EMPTY_CODE;
     const uint64_t gt = (uint64_t)(pp.ltile_begin + tl) * pp.tile_count + pp.tile_index;
-    if (gt >= (uint64_t)pp.tiles_x * pp.tiles_y || sc.n_leaf_prims == 0) { table[tl] = make_int4(EMPTY, EMPTY, EMPTY, EMPTY); return; }
+    constexpr int K = RT_ENTRY_K;
+    int4* const out = table + (size_t)te * (K / 4);
+    if (gt >= (uint64_t)pp.tiles_x * pp.tiles_y || sc.n_leaf_prims == 0) {
+        for (int k = 0; k < K / 4; ++k) out[k] = make_int4(EMPTY, EMPTY, EMPTY, EMPTY);
+        return;
+    }
     const uint32_t ty = (uint32_t)(gt / pp.tiles_x), tx = (uint32_t)(gt - (uint64_t)ty * pp.tiles_x);
-    const uint32_t x_lo = tx * 8u, x_hi = min(x_lo + 8u, sc.width), r_lo = ty * 8u, r_hi = min(r_lo + 8u, sc.height);
+    const uint32_t x_lo = min(tx * 8u + (sub % S) * SW, sc.width), x_hi = min(x_lo + SW, sc.width);
+    const uint32_t r_lo = min(ty * 8u + (sub / S) * SW, sc.height), r_hi = min(r_lo + SW, sc.height);
     // sample positions of the tile (primary_ray): px = x + off_x + [0, 1], py = (height - 1 - row) + off_y + [0, 1]
     const double pxl = (double)x_lo + (double)pp.off_x - RT_ENTRY_PAD, pxh = (double)x_hi + (double)pp.off_x + RT_ENTRY_PAD;
     const double pyl = (double)(sc.height - r_hi) + (double)pp.off_y - RT_ENTRY_PAD, pyh = (double)(sc.height - r_lo) + (double)pp.off_y + RT_ENTRY_PAD;
@@ -1121,14 +1162,16 @@ __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, i
     }
     const double tmax2 = tmax < 1e150 ? tmax * tmax * (1.0 + 4e-3) : __builtin_inf();
     // frontier: codes, squared distance of the box from the eye (the order in which the rays will try them), "not to be expanded"
-    int32_t code[4] = {0, EMPTY, EMPTY, EMPTY};
-    double key[4] = {0.0, 0.0, 0.0, 0.0};
-    bool fin[4] = {false, false, false, false};
+    int32_t code[K];
+    double key[K];
+    bool fin[K];
+    for (int k = 0; k < K; ++k) { code[k] = EMPTY; key[k] = 0.0; fin[k] = false; }
+    code[0] = 0;
     int n = 1;
     for (int iter = 0; iter < 96; ++iter) {
         int i = -1;
 #pragma unroll
-        for (int k = 3; k >= 0; --k) if (k < n && code[k] >= 0 && !fin[k]) i = k;
+        for (int k = K - 1; k >= 0; --k) if (k < n && code[k] >= 0 && !fin[k]) i = k;
         if (i < 0) break;
         const float4* __restrict__ base = sc.nodes + 4 * (size_t)code[i];
         const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
@@ -1159,7 +1202,7 @@ __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, i
             out = out || d2 > tmax2;
             if (!out) { hc[nh] = ch[k]; hk[nh] = d2; nh++; }
         }
-        if (n - 1 + nh <= 4) {
+        if (n - 1 + nh <= K && nh <= RT_ENTRY_MAXH) {
             // the node gives way to the children the pyramid reaches
             for (int k = i; k + 1 < n; ++k) { code[k] = code[k + 1]; key[k] = key[k + 1]; fin[k] = fin[k + 1]; }
             n--;
@@ -1172,7 +1215,8 @@ __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, i
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
             if (key[b] < key[a]) { const double tk = key[a]; key[a] = key[b]; key[b] = tk; const int32_t tc = code[a]; code[a] = code[b]; code[b] = tc; }
-    table[tl] = make_int4(n > 0 ? code[0] : EMPTY, n > 1 ? code[1] : EMPTY, n > 2 ? code[2] : EMPTY, n > 3 ? code[3] : EMPTY);
+    for (int k = 0; k < K / 4; ++k)
+        out[k] = make_int4(n > 4 * k ? code[4 * k] : EMPTY, n > 4 * k + 1 ? code[4 * k + 1] : EMPTY, n > 4 * k + 2 ? code[4 * k + 2] : EMPTY, n > 4 * k + 3 ? code[4 * k + 3] : EMPTY);
 }
 
 // ---------------------------------------------------------------- shading
@@ -1460,6 +1504,10 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 // padding slot: not a ray
             } else if (code == HIT_MISS) {
                 rad = thr * mk(sc.bg[0], sc.bg[1], sc.bg[2]); has_rad = true;   // raytrace.rs:95
+            } else if (last && sc.no_emitters) {
+                // the path's last ray has hit something in a scene without emitters: whatever the material does, the scattered ray
+                // returns black (raytrace.rs:52-54) and there is no light to sample -- nothing to gather, nothing to compute
+                // (k_closest_hit stopped at the first hit it found for this ray: `code` need not be the closest one)
             } else {
                 float t = H.x;
                 f3 nrm;
@@ -1693,7 +1741,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             const d3 nd64 = exact ? mkd(join64(dir_out.x, d_lo_x), join64(dir_out.y, d_lo_y), join64(dir_out.z, d_lo_z)) : dither64(dir_out, dh);
             auto test = [&](uint32_t c, double& t1) -> bool {
                 const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)c + 1);
-                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code)
+                const double2 w0 = r64[0], w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];   // (re-read: cheaper than 18 live registers across the scatter code; kept in LDS instead: C4 -0.5 %, C5 unchanged)
                 double a1, b1;
                 return tri_hit_ref(p64, nd64, mkd(w0.x, w0.y, w1.x), mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x), t1, a1, b1);
             };
@@ -1905,21 +1953,21 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
 }
 void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hipStream_t st) {
-    hipLaunchKernelGGL(k_tile_entry, dim3(cdiv(pp.npix_pad >> 6, 64)), dim3(64), 0, st, sc, pp, table);
+    hipLaunchKernelGGL(k_tile_entry, dim3(cdiv((uint64_t)(pp.npix_pad >> 6) * (RT_ENTRY_SUB * RT_ENTRY_SUB), 64)), dim3(64), 0, st, sc, pp, table);
 }
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
-                        uint32_t max_rays, bool counters, TileEntry entry, hipStream_t st) {
+                        uint32_t max_rays, bool counters, TileEntry entry, bool any_hit, hipStream_t st) {
     uint32_t per_cu = HIT_BLOCKS_PER_CU;
     if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
     const size_t lds = 0;
     const dim3 g(blocks), b(256);
     if (sc.n_tris) {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
-        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
+        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
     } else {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
-        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry);
+        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
+        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
     }
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,

@@ -354,3 +354,38 @@ def test_tile_entry_points_change_nothing():
         assert n_on < n_off
     finally:
         off.close(); on.close()
+
+
+def test_last_rays_that_stop_at_their_first_hit_change_nothing():
+    """In a scene without emitters (no Emissive / Texture material, hence no lights) the last ray of a path contributes the
+    background if it escapes and nothing otherwise (raytrace.rs:52-54,95), so k_closest_hit ends its traversal at the first hit
+    and k_shade gathers nothing for it.  Renders are identical, value by value, with that switched off (RTAMD_ANY_HIT=0), at
+    depth 1 (the primary rays are the last ones), 2 and 5, on spheres (C3), the mesh over a plane (C4) and both (C5); a scene
+    WITH emitters (scenes/spheres: Emissive plane and sphere) does not take the path at all."""
+    os.environ["RTAMD_ANY_HIT"] = "0"
+    try:
+        off = rt.Context(0)
+    finally:
+        del os.environ["RTAMD_ANY_HIT"]
+    on = rt.Context(0)
+    try:
+        for name, sc in (("c3", scenegen.scene_c3(323, 181)), ("c4", scenegen.scene_c4(387, 213, 120, 60)), ("c5", scenegen.scene_c5(645, 363, 200, 100))):
+            scene = rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"])
+            off.upload(scene); on.upload(scene)
+            for depth in (1, 2, 5):
+                p = rt.RenderParams("jitter:3", depth=depth, seed=31 + depth, counters=True)
+                off.stats_reset(); on.stats_reset()
+                a, _ = off.render_image(p)
+                b, _ = on.render_image(p)
+                assert np.array_equal(a, b), "%s depth %d: renders differ in %d values" % (name, depth, (a != b).sum())
+                so, sn = off.stats(), on.stats()
+                assert so["rays_total"] == sn["rays_total"] and so["rays_per_iteration"] == sn["rays_per_iteration"]
+                assert sn["nodes_visited"] < so["nodes_visited"], (name, depth)
+        golden = os.path.join(GOLDEN, "scenes", "spheres", "spheres.yaml")
+        off.upload(rt.Scene.load(golden, base_dir=GOLDEN)); on.upload(rt.Scene.load(golden, base_dir=GOLDEN))
+        p = rt.RenderParams("uniform:2", depth=3, seed=3, counters=True, max_shadow_generations=1)
+        off.stats_reset(); on.stats_reset()
+        off.render_image(p); on.render_image(p)
+        assert off.stats()["nodes_visited"] == on.stats()["nodes_visited"]
+    finally:
+        off.close(); on.close()
