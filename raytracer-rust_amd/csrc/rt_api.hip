@@ -51,6 +51,9 @@ struct rt_context {
     std::vector<void*> scene_allocs;
     int bvh_builder = 0;      // 0: host binned SAH (bvh.cpp), 1: GPU LBVH (bvh_gpu.hip)
     bool any_hit_last = true; // the paths' last rays stop at their first hit in scenes without emitters; RTAMD_ANY_HIT=0 (read at rt_context_create, applied at scene upload): closest hit and full shading as for every ray (A/B, tests)
+    bool gen_primary = false; // RTAMD_GEN_PRIMARY=1: iteration 0 forms the primary rays itself instead of reading what k_raygen wrote.  Measured and left
+                              // off: k_raygen's 0.9 ms per 133 M paths go, but k_closest_hit (+0.65 ms) and k_shade (+0.8 ms) pay more for forming the ray
+                              // again than they save in reads (C5 24.75 -> 25.3 ms per 64-spp step, C3 14.8 -> 15.2)
     bool tile_entry = true;   // primary rays enter the BVH at their tile's entry points (k_tile_entry); RTAMD_TILE_ENTRY=0: at the root (A/B, tests)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_prims = 0;
     double bvh_build_ms = 0;
@@ -199,6 +202,7 @@ int rt_context_create(int device_id, rt_context** out) {
         return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
     rt_context* ctx = new rt_context();
     if (const char* e = getenv("RTAMD_TILE_ENTRY")) ctx->tile_entry = atoi(e) != 0;
+    if (const char* e = getenv("RTAMD_GEN_PRIMARY")) ctx->gen_primary = atoi(e) != 0;
     if (const char* e = getenv("RTAMD_ANY_HIT")) ctx->any_hit_last = atoi(e) != 0;
     ctx->device = device_id;
     ctx->cfg.n_cu = (uint32_t)prop.multiProcessorCount;
@@ -694,7 +698,11 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             pp.clear_radiance = (sc.n_lights > 0 || hits_only || p->depth == 0) ? 1u : 0u;
             if (pp_out) *pp_out = pp;
             HIP_TRY(ctx, hipMemsetAsync(ws.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
-            launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
+            // iteration 0 forms the primary rays itself (k_closest_hit<.., GEN>, k_shade<.., 2>) unless something needs what k_raygen
+            // leaves behind: the queue words (rt_primary_hits / rt_primary_rays) or cleared radiance words (scenes with lights)
+            const bool gen = ctx->gen_primary && !hits_only && p->depth > 0 && !pp.clear_radiance;
+            if (gen) launch_pass_begin(ws.ctl, pp.n_paths, st);
+            else launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
             // entry points of the tiles' primary rays into the BVH (k_tile_entry): one int4 per tile of the pass, kept in the first
             // words of queue 1's word f, which nothing touches before k_shade of iteration 0 writes the rays of iteration 1
             TileEntry entry{nullptr, pp.npix_pad, pp.inv_npix_pad};
@@ -732,13 +740,13 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                 const int last = it + 1 < depth ? 0 : (it + 1 < iters ? 1 : 2);
                 // the paths' last rays in a scene without emitters only ask WHETHER they hit (see k_closest_hit)
                 const bool any_hit = !hits_only && last != 0 && sc.no_emitters;
-                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, it == 0 ? entry : TileEntry{nullptr, 0u, 0.0}, any_hit, st);
+                launch_closest_hit(ctx->cfg, sc, qi, ws.hits, ws.ctl, (int)it, capacity, max_rays, counters, it == 0 ? entry : TileEntry{nullptr, 0u, 0.0}, any_hit, gen && it == 0 ? &pp : nullptr, st);
                 if (timing) {
                     HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].second, st));
                     ctx->events_used++;
                 }
                 if (hits_only) break;
-                launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, st);
+                launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, gen && it == 0 ? &pp : nullptr, st);
             }
             if (!hits_only) launch_accumulate(sc, pp, ws.radiance, accum_dev, st);
             launch_stats(ws.ctl, ctx->stats_dev, capacity, st);

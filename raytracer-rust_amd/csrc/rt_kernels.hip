@@ -641,9 +641,13 @@ constexpr uint32_t REFILL_IDLE_LANES = RT_REFILL;   // refill the wave once this
 // lights): such a ray contributes the background if it escapes and nothing otherwise (raytrace.rs:52-54,95: whatever it hits
 // scatters into a ray that returns black), so WHICH surface it hits first does not matter and its traversal ends at the first
 // hit it finds.  A candidate at t ~ 0 that f32 cannot decide (AUX_NEAR_BIT) is no such hit: it still goes to k_shade's f64 test.
-template <bool COUNT, bool TRIS>   // TRIS: the scene has triangles (what Best::aux holds, see consider)
+// GEN: iteration 0 without k_raygen -- a lane forms the primary ray of the path slot it takes (primary_ray; the direction from the
+// fast normalisation, which is all a traversal that only ranks candidates needs) instead of reading it from the queue, and
+// k_shade<.., 2> forms it again (exactly, in scenes with triangles): 32 bytes per path less to write and 32 to read, one launch
+// less, and a refill of primary rays waits for no memory at all.
+template <bool COUNT, bool TRIS, bool GEN>   // TRIS: the scene has triangles (what Best::aux holds, see consider)
 __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene sc, RayQueue q, float2* __restrict__ hits, uint32_t* __restrict__ ctl,
-                                                    int it, uint32_t capacity, TileEntry entry, int any_hit) {
+                                                    int it, uint32_t capacity, TileEntry entry, int any_hit, PassParams pp) {
     // per-lane traversal stacks: the first LDS_STACK levels in LDS, laid out [wave][level][lane]
     // (bank = lane: conflict-free), deeper levels (rare) in a global overflow area
     const uint32_t lane = lane_id();
@@ -764,7 +768,8 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                         // A refill is a chain of dependent memory round trips during which the wave's other
                         // lanes wait, so it is kept to one: the ray words a and b.  Planes and big spheres come
                         // from LDS; whether the ray re-hits the triangle it starts on was decided by k_shade.
-                        float4 A = ld_stream(&q.a[ray]), B;
+                        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B;
+                        if (!GEN) A = ld_stream(&q.a[ray]);
                         // where the ray enters the BVH: the root, or for a primary ray the entry points of its 8x8 tile (k_tile_entry)
                         int4 F = make_int4(0, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
                         auto entry_index = [&]() -> size_t {
@@ -781,7 +786,13 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
 #else
                         if (it == 0 && entry.table) F = entry.table[entry_index()];
 #endif
-                        if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
+                        if (GEN) {
+                            uint32_t rng_;
+                            double gx = 0.0, gy = 0.0, gz = 0.0;
+                            const bool ok = primary_ray(sc, pp, ray, rng_, gx, gy, gz, false);
+                            B = make_float4((float)gy, (float)gz, __uint_as_float(ok ? SRC_NONE : SRC_INVALID), 0.f);
+                            A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], (float)gx);
+                        } else if (it == 0) {   // primary ray: (d, rng) only, see k_raygen
                             B = make_float4(A.y, A.z, __uint_as_float(A.x == 0.f && A.y == 0.f && A.z == 0.f ? SRC_INVALID : SRC_NONE), 0.f);
                             A = make_float4(sc.eye[0], sc.eye[1], sc.eye[2], A.x);
                         } else {
@@ -1343,10 +1354,11 @@ __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t cod
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
-template <bool TRIS, bool PRIMARY>   // PRIMARY: iteration 0, the queue holds 16-byte primary rays (k_raygen)
+template <bool TRIS, int PRIMARY>   // PRIMARY: iteration 0; 1: the queue holds 16-byte primary rays (k_raygen), 2: no queue, the ray is formed here (see k_closest_hit, GEN)
 __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
-                                               uint32_t capacity) {
+                                               uint32_t capacity, PassParams pp) {
+    constexpr bool GEN = PRIMARY == 2;
     __shared__ uint32_t lds_alloc[17];
     // RT_SHADE_SORT (off: measured and dropped, kept as a variant).  The rays of a block round sorted by what they hit before they
     // are shaded (scenes with triangles): a triangle hit costs two evaluations of the reference's f64 determinants (hit point,
@@ -1372,7 +1384,8 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA, nC = nA;
     float2 nH = make_float2(0.f, 0.f);
     auto load_round = [&](uint32_t j) {
-        nA = ld_stream(&qi.a[j]); nH = ld_stream(&hits[j]);
+        if (!GEN) nA = ld_stream(&qi.a[j]);
+        nH = ld_stream(&hits[j]);
         if (!PRIMARY) { nB = ld_stream(&qi.b[j]); nC = ld_stream(&qi.c[j]); }
     };
     // ... and the first word of the shading record of the next round's hit (normal / material / kind) right behind the claim, when
@@ -1436,7 +1449,17 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         if (__float_as_uint(H.y) != HIT_INVALID) {
             f3 o, d;
             uint32_t src = SRC_NONE;
-            if (PRIMARY) {   // primary ray: (d, rng) only, see k_raygen
+            uint4 E0g = make_uint4(0u, 0u, 0u, 0u);   // GEN: the low bits of the f64 direction (what k_raygen writes to queue word e)
+            if (GEN) {
+                // the ray k_raygen would have written for this slot (the same function, the same bits)
+                double gx = 0.0, gy = 0.0, gz = 0.0;
+                (void)primary_ray(sc, pp, my, rng, gx, gy, gz, RT_PRIMARY_REF64 && TRIS);
+                o = mk(sc.eye[0], sc.eye[1], sc.eye[2]);
+                d = mk((float)gx, (float)gy, (float)gz);
+                if (RT_PRIMARY_REF64 && TRIS) { split64(gx, d.x, E0g.x); split64(gy, d.y, E0g.y); split64(gz, d.z, E0g.z); }
+                pid = my;
+                thr = mk(1.f, 1.f, 1.f);
+            } else if (PRIMARY) {   // primary ray: (d, rng) only, see k_raygen
                 o = mk(sc.eye[0], sc.eye[1], sc.eye[2]); d = mk(A.x, A.y, A.z);
                 pid = my;
                 thr = mk(1.f, 1.f, 1.f);
@@ -1473,7 +1496,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     // sequence (primary_ray), and at exactly representable coordinates what the ray does on the triangle it
                     // reaches depends on them.  (Not read for a hit on a sphere: its hit point and normal mix every bit
                     // anew, as for the exact specular directions; RT_PRIMARY_REF64 = 2 reads it there too.)
-                    const uint4 E0 = ld_stream(&qi.e[my]);
+                    const uint4 E0 = GEN ? E0g : ld_stream(&qi.e[my]);
                     d64 = mkd(join64(d.x, E0.x), join64(d.y, E0.y), join64(d.z, E0.z));
                 } else {
                     const bool exact_d = RT_DIR_REF64 && carried && (src & SRC_D_BIT), self_ray = carried && (src >> 30) == 1u;
@@ -1934,6 +1957,11 @@ __global__ __launch_bounds__(256) void k_calib_gather(const float4* __restrict__
     if (acc == 12345.678f) sink[0] = acc;   // keeps the loads alive
 }
 
+// the pass's number of path slots as the ray count of iteration 0 (what k_raygen does when it runs)
+__global__ void k_pass_begin(uint32_t* __restrict__ ctl, uint32_t n_paths) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = n_paths;
+}
+
 // adds the pass's counters into the persistent 64-bit statistics
 __global__ void k_stats(const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ stats, uint32_t capacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1952,35 +1980,47 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
     uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
 }
+void launch_pass_begin(uint32_t* ctl, uint32_t n_paths, hipStream_t st) {
+    hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, ctl, n_paths);
+}
 void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_entry, dim3(cdiv((uint64_t)(pp.npix_pad >> 6) * (RT_ENTRY_SUB * RT_ENTRY_SUB), 64)), dim3(64), 0, st, sc, pp, table);
 }
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
-                        uint32_t max_rays, bool counters, TileEntry entry, bool any_hit, hipStream_t st) {
+                        uint32_t max_rays, bool counters, TileEntry entry, bool any_hit, const PassParams* gen, hipStream_t st) {
     uint32_t per_cu = HIT_BLOCKS_PER_CU;
     if (const char* e = getenv("RTAMD_HIT_BLOCKS_PER_CU")) per_cu = std::min<uint32_t>(HIT_BLOCKS_PER_CU, std::max(1, atoi(e)));   // tuning experiments only
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1, cdiv(max_rays, 256)));
     const size_t lds = 0;
     const dim3 g(blocks), b(256);
+    const int ah = any_hit ? 1 : 0;
+    PassParams pp0{};
+    const PassParams& pp = gen ? *gen : pp0;
+#define RT_HIT_LAUNCH(C, T, G) hipLaunchKernelGGL((k_closest_hit<C, T, G>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, ah, pp)
     if (sc.n_tris) {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
-        else hipLaunchKernelGGL((k_closest_hit<false, true>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
+        if (gen) { if (counters) RT_HIT_LAUNCH(true, true, true); else RT_HIT_LAUNCH(false, true, true); }
+        else { if (counters) RT_HIT_LAUNCH(true, true, false); else RT_HIT_LAUNCH(false, true, false); }
     } else {
-        if (counters) hipLaunchKernelGGL((k_closest_hit<true, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
-        else hipLaunchKernelGGL((k_closest_hit<false, false>), g, b, lds, st, sc, q, hits, ctl, it, capacity, entry, any_hit ? 1 : 0);
+        if (gen) { if (counters) RT_HIT_LAUNCH(true, false, true); else RT_HIT_LAUNCH(false, false, true); }
+        else { if (counters) RT_HIT_LAUNCH(true, false, false); else RT_HIT_LAUNCH(false, false, false); }
     }
+#undef RT_HIT_LAUNCH
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
-                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, hipStream_t st) {
+                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, const PassParams* gen, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
     const dim3 g(blocks), b(SHADE_THREADS);
+    PassParams pp0{};
+    const PassParams& pp = gen ? *gen : pp0;
+#define RT_SHADE_LAUNCH(T, P) hipLaunchKernelGGL((k_shade<T, P>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity, pp)
     if (sc.n_tris) {
-        if (it == 0) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
-        else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+        if (it == 0) { if (gen) RT_SHADE_LAUNCH(true, 2); else RT_SHADE_LAUNCH(true, 1); }
+        else RT_SHADE_LAUNCH(true, 0);
     } else {
-        if (it == 0) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
-        else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity);
+        if (it == 0) { if (gen) RT_SHADE_LAUNCH(false, 2); else RT_SHADE_LAUNCH(false, 1); }
+        else RT_SHADE_LAUNCH(false, 0);
     }
+#undef RT_SHADE_LAUNCH
 }
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(pp.npix_pad, 256)), dim3(256), 0, st, sc, pp, radiance, accum);

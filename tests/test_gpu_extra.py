@@ -389,3 +389,36 @@ def test_last_rays_that_stop_at_their_first_hit_change_nothing():
         assert off.stats()["nodes_visited"] == on.stats()["nodes_visited"]
     finally:
         off.close(); on.close()
+
+
+def test_primary_rays_formed_in_iteration_0_change_nothing():
+    """RTAMD_GEN_PRIMARY=1 (off by default: measured slower): without k_raygen, k_closest_hit and k_shade of iteration 0 form
+    the primary ray of a path slot themselves (primary_ray, the function k_raygen calls).  Scenes without triangles: the two renders are identical value by value (both kernels see the very f32 direction
+    k_raygen would have written).  Scenes with triangles: k_shade works on the same exact f64 direction either way, the traversal
+    ranks its candidates along the fast-normalised direction (one f32 ulp from the truncated exact one at most), so a ray within an
+    ulp of an edge may land on the neighbour: all but a few pixels in 100,000 are identical, and the means agree to 1e-5."""
+    os.environ["RTAMD_GEN_PRIMARY"] = "1"
+    try:
+        on = rt.Context(0)
+    finally:
+        del os.environ["RTAMD_GEN_PRIMARY"]
+    off = rt.Context(0)
+    try:
+        for name, sc in (("c3", scenegen.scene_c3(323, 181)), ("c4", scenegen.scene_c4(387, 213, 120, 60)), ("c5", scenegen.scene_c5(645, 363, 200, 100))):
+            scene = rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"])
+            off.upload(scene); on.upload(scene)
+            for kw in (dict(ssaa="jitter:3", depth=4), dict(ssaa="uniform:2", depth=1), dict(ssaa="jitter:2", depth=3, tile_index=2, tile_count=5),
+                       dict(ssaa="jitter:4", depth=2, sample_begin=3, sample_end=11, max_paths_per_pass=64 * 700)):
+                p = rt.RenderParams(kw.pop("ssaa"), seed=9, **kw)
+                off.stats_reset(); on.stats_reset()
+                a, _ = off.render_image(p)
+                b, _ = on.render_image(p)
+                assert off.stats()["paths"] == on.stats()["paths"] and off.stats()["rays_per_iteration"][0] == on.stats()["rays_per_iteration"][0]
+                differ = (a != b).any(axis=2).mean()
+                print("%s %s: %.2e of the pixels differ" % (name, kw, differ))
+                if name == "c3":
+                    assert differ == 0.0
+                else:
+                    assert differ < 2e-4 and abs(a.mean(dtype=np.float64) - b.mean(dtype=np.float64)) <= 1e-5 * a.mean(dtype=np.float64)
+    finally:
+        off.close(); on.close()
