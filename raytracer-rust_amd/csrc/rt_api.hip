@@ -701,14 +701,18 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             // iteration 0 forms the primary rays itself (k_closest_hit<.., GEN>, k_shade<.., 2>) unless something needs what k_raygen
             // leaves behind: the queue words (rt_primary_hits / rt_primary_rays) or cleared radiance words (scenes with lights)
             const bool gen = ctx->gen_primary && !hits_only && p->depth > 0 && !pp.clear_radiance;
-            if (gen) launch_pass_begin(ws.ctl, pp.n_paths, st);
-            else launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
-            // entry points of the tiles' primary rays into the BVH (k_tile_entry): one int4 per tile of the pass, kept in the first
+            // entry points of the tiles' primary rays into the BVH (k_tile_entry): 4 or 8 words per tile of the pass, kept in the first
             // words of queue 1's word f, which nothing touches before k_shade of iteration 0 writes the rays of iteration 1
             TileEntry entry{nullptr, pp.npix_pad, pp.inv_npix_pad};
-            if (ctx->tile_entry && sc.n_leaf_prims && (hits_only || p->depth > 0)) {
-                entry.table = reinterpret_cast<const int4*>(ws.q[1].f);
-                launch_tile_entry(sc, pp, reinterpret_cast<int4*>(ws.q[1].f), st);
+            const bool with_entry = ctx->tile_entry && sc.n_leaf_prims && (hits_only || p->depth > 0);
+            if (with_entry) entry.table = reinterpret_cast<const int4*>(ws.q[1].f);
+            if (gen) {
+                launch_pass_begin(ws.ctl, pp.n_paths, st);
+                if (with_entry) launch_tile_entry(sc, pp, reinterpret_cast<int4*>(ws.q[1].f), st);
+            } else if (with_entry) {
+                launch_raygen_entry(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, reinterpret_cast<int4*>(ws.q[1].f), st);   // both in one launch
+            } else {
+                launch_raygen(ctx->cfg, sc, pp, ws.q[0], ws.radiance, ws.ctl, capacity, st);
             }
             {   // primary rays = pixels of the pass's tiles that lie inside the image
                 uint64_t px = 0;

@@ -12,6 +12,8 @@ struct LaunchCfg {
 
 void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue q, float4* radiance, uint32_t* ctl,
                    uint32_t capacity, hipStream_t st);
+void launch_raygen_entry(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue q, float4* radiance, uint32_t* ctl, int4* table,
+                         hipStream_t st);   // k_raygen and k_tile_entry in one launch
 void launch_pass_begin(uint32_t* ctl, uint32_t n_paths, hipStream_t st);
 void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hipStream_t st);
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,

@@ -259,10 +259,11 @@ __device__ __forceinline__ bool primary_ray(const DevScene& sc, const PassParams
 #endif
 }
 
-__global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
-                                                uint32_t* __restrict__ ctl, uint32_t capacity) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < pp.n_paths; pid += stride) {   // n_paths % 64 == 0: wave-uniform
+// (block0: the first block of the launch that does this work -- the blocks before it find the tiles' entry points, k_raygen_entry)
+__device__ __forceinline__ void raygen_body(const DevScene& sc, const PassParams& pp, const RayQueue& q, float4* __restrict__ radiance,
+                                            uint32_t* __restrict__ ctl, uint32_t block0) {
+    const uint32_t stride = (gridDim.x - block0) * blockDim.x;
+    for (uint32_t pid = (blockIdx.x - block0) * blockDim.x + threadIdx.x; pid < pp.n_paths; pid += stride) {   // n_paths % 64 == 0: wave-uniform
         if (pp.clear_radiance) radiance[pid] = make_float4(0.f, 0.f, 0.f, 0.f);   // (scenes without lights: every path stores its radiance exactly once, k_shade)
         // slot == path id: no compaction (one atomic per wave on a single counter costs more than the
         // whole kernel).  Padding slots of border tiles are flagged and skipped downstream.
@@ -284,7 +285,11 @@ __global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQ
         }
         st_stream(&q.a[pid], A);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
+    if (blockIdx.x == block0 && threadIdx.x == 0) ctl[CTL_QCOUNT + 0] = pp.n_paths;
+}
+__global__ __launch_bounds__(256) void k_raygen(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance,
+                                                uint32_t* __restrict__ ctl, uint32_t capacity) {
+    raygen_body(sc, pp, q, radiance, ctl, 0u);
 }
 
 // ---------------------------------------------------------------- closest hit
@@ -783,17 +788,16 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                             constexpr uint32_t S = RT_ENTRY_SUB, W = 8u / S;
                             return (size_t)(pl >> 6) * (S * S) + (((pl >> 3) & 7u) / W) * S + (pl & 7u) / W;
                         };
-#if RT_ENTRY_K > 4 || RT_ENTRY_K_TRIS > 4
                         constexpr int EK = TRIS ? RT_ENTRY_K_TRIS : RT_ENTRY_K;
-                        int4 F1 = make_int4(CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
+                        int4 Fx[EK / 4];
+#pragma unroll
+                        for (int k = 1; k < EK / 4; ++k) Fx[k] = make_int4(CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE, CHILD_EMPTY_CODE);
                         if (it == 0 && entry.table) {
                             const int4* __restrict__ fe = entry.table + (EK / 4) * entry_index();
                             F = fe[0];
-                            if (EK > 4) F1 = fe[1];
+#pragma unroll
+                            for (int k = 1; k < EK / 4; ++k) Fx[k] = fe[k];
                         }
-#else
-                        if (it == 0 && entry.table) F = entry.table[entry_index()];
-#endif
                         if (GEN) {
                             uint32_t rng_;
                             double gx = 0.0, gy = 0.0, gz = 0.0;
@@ -864,12 +868,13 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 stk[0] = (uint32_t)STACK_SENTINEL;
 #endif
                                 sp = 1;
-#if RT_ENTRY_K > 4 || RT_ENTRY_K_TRIS > 4
-                                if (F1.w != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.w, 0u);
-                                if (F1.z != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.z, 0u);
-                                if (F1.y != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.y, 0u);
-                                if (F1.x != CHILD_EMPTY_CODE) push(sp, (uint32_t)F1.x, 0u);
-#endif
+#pragma unroll
+                                for (int k = EK / 4 - 1; k >= 1; --k) {
+                                    if (Fx[k].w != CHILD_EMPTY_CODE) push(sp, (uint32_t)Fx[k].w, 0u);
+                                    if (Fx[k].z != CHILD_EMPTY_CODE) push(sp, (uint32_t)Fx[k].z, 0u);
+                                    if (Fx[k].y != CHILD_EMPTY_CODE) push(sp, (uint32_t)Fx[k].y, 0u);
+                                    if (Fx[k].x != CHILD_EMPTY_CODE) push(sp, (uint32_t)Fx[k].x, 0u);
+                                }
                                 if (F.w != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.w, 0u);
                                 if (F.z != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.z, 0u);
                                 if (F.y != CHILD_EMPTY_CODE) push(sp, (uint32_t)F.y, 0u);
@@ -1102,9 +1107,9 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
 #ifndef RT_ENTRY_PAD
 #define RT_ENTRY_PAD 0.05
 #endif
-__global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, int4* __restrict__ table) {
+__device__ __forceinline__ void tile_entry_body(const DevScene& sc, const PassParams& pp, int4* __restrict__ table) {
     constexpr uint32_t S = RT_ENTRY_SUB, SW = 8u / S;
-    const uint32_t te = blockIdx.x * blockDim.x + threadIdx.x;   // (local tile of the pass, part of the tile)
+    const uint32_t te = blockIdx.x * 64u + threadIdx.x;   // (local tile of the pass, part of the tile): 64 per block
     if (te >= (pp.npix_pad >> 6) * (S * S)) return;
     const uint32_t tl = te / (S * S), sub = te % (S * S);
     const int32_t EMPTY = CHILD_EMPTY_CODE;
@@ -1182,39 +1187,41 @@ __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, i
     }
     const double tmax2 = tmax < 1e150 ? tmax * tmax * (1.0 + 4e-3) : __builtin_inf();
     // frontier: codes, squared distance of the box from the eye (the order in which the rays will try them), "not to be expanded"
-    int32_t code[KMAX];
-    double key[KMAX];
-    bool fin[KMAX];
-    for (int k = 0; k < KMAX; ++k) { code[k] = EMPTY; key[k] = 0.0; fin[k] = false; }
-    code[0] = 0;
+    // (the frontier lives in LDS, [entry][thread]: indexed by run-time values, registers would turn into scratch memory)
+    __shared__ int32_t s_code[KMAX][64];
+    __shared__ double s_key[KMAX][64];
+    const uint32_t tx_ = threadIdx.x;
+#define code(k) s_code[k][tx_]
+#define key(k) s_key[k][tx_]
+    for (int k = 0; k < KMAX; ++k) { code(k) = EMPTY; key(k) = 0.0; }
+    code(0) = 0;
+    uint32_t fin = 0u;   // bit k: entry k is not to be expanded
     int n = 1;
     for (int iter = 0; iter < 96; ++iter) {
-        int i = -1;
-#pragma unroll
-#if RT_ENTRY_NEAREST
         // nearest first: most rays end in the nearest part of what the pyramid reaches, so that part gets the entry points
-        for (int k = KMAX - 1; k >= 0; --k) if (k < n && code[k] >= 0 && !fin[k] && (i < 0 || key[k] <= key[i])) i = k;
-#else
-        for (int k = KMAX - 1; k >= 0; --k) if (k < n && code[k] >= 0 && !fin[k]) i = k;
-#endif
+        int i = -1;
+        double ki = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double kk = key(k);
+            if (code(k) >= 0 && !((fin >> k) & 1u) && (i < 0 || (RT_ENTRY_NEAREST && kk < ki))) { i = k; ki = kk; }
+        }
         if (i < 0) break;
-        const float4* __restrict__ base = sc.nodes + 4 * (size_t)code[i];
+        const float4* __restrict__ base = sc.nodes + 4 * (size_t)code(i);
         const float4 L0 = base[0], L1 = base[1], L2 = base[2], L3 = base[3];
         const double sx = (double)fabsf(__uint_as_float(__float_as_uint(L0.w) << 23)), sy = (double)L3.z, sz = (double)L3.w;
         const uint32_t ql[3] = {__float_as_uint(L2.x), __float_as_uint(L2.y), __float_as_uint(L2.z)};
         const uint32_t qh[3] = {__float_as_uint(L2.w), __float_as_uint(L3.x), __float_as_uint(L3.y)};
         const int32_t ch[4] = {__float_as_int(L1.x), __float_as_int(L1.y), __float_as_int(L1.z), __float_as_int(L1.w)};
-        int32_t hc[4];
+        bool hit[4];
         double hk[4];
         int nh = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (ch[k] == EMPTY) continue;
             const d3 lo = mkd((double)L0.x + (double)((ql[0] >> (8 * k)) & 0xFFu) * sx, (double)L0.y + (double)((ql[1] >> (8 * k)) & 0xFFu) * sy,
                               (double)L0.z + (double)((ql[2] >> (8 * k)) & 0xFFu) * sz);
             const d3 hi = mkd((double)L0.x + (double)((qh[0] >> (8 * k)) & 0xFFu) * sx, (double)L0.y + (double)((qh[1] >> (8 * k)) & 0xFFu) * sy,
                               (double)L0.z + (double)((qh[2] >> (8 * k)) & 0xFFu) * sz);
-            bool out = false;
+            bool out = ch[k] == EMPTY;
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) {
                 const d3 nn = pn[pl];
@@ -1225,23 +1232,43 @@ __global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, i
                          ddz = fmax(fmax(lo.z - eye.z, eye.z - hi.z), 0.0);
             const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             out = out || d2 > tmax2;
-            if (!out) { hc[nh] = ch[k]; hk[nh] = d2; nh++; }
+            hit[k] = !out; hk[k] = d2;
+            nh += out ? 0 : 1;
         }
         if (n - 1 + nh <= K && nh <= RT_ENTRY_MAXH) {
-            // the node gives way to the children the pyramid reaches
-            for (int k = i; k + 1 < n; ++k) { code[k] = code[k + 1]; key[k] = key[k + 1]; fin[k] = fin[k + 1]; }
+            // the node gives way to the children the pyramid reaches (the last entry takes its place: the order is made at the end)
             n--;
-            for (int k = 0; k < nh; ++k) { code[n] = hc[k]; key[n] = hk[k]; fin[n] = false; n++; }
+            code(i) = code(n); key(i) = key(n);
+            fin = (fin & ~(1u << i)) | (((fin >> n) & 1u) << i);
+            fin &= ~(1u << n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (hit[k]) { code(n) = ch[k]; key(n) = hk[k]; n++; }
         } else {
-            fin[i] = true;
+            fin |= 1u << i;
         }
     }
     // nearest first
     for (int a = 0; a < n; ++a)
-        for (int b = a + 1; b < n; ++b)
-            if (key[b] < key[a]) { const double tk = key[a]; key[a] = key[b]; key[b] = tk; const int32_t tc = code[a]; code[a] = code[b]; code[b] = tc; }
+        for (int b = a + 1; b < n; ++b) {
+            const double ka = key(a), kb = key(b);
+            if (kb < ka) { key(a) = kb; key(b) = ka; const int32_t tc = code(a); code(a) = code(b); code(b) = tc; }
+        }
     for (int k = 0; k < K / 4; ++k)
-        out[k] = make_int4(n > 4 * k ? code[4 * k] : EMPTY, n > 4 * k + 1 ? code[4 * k + 1] : EMPTY, n > 4 * k + 2 ? code[4 * k + 2] : EMPTY, n > 4 * k + 3 ? code[4 * k + 3] : EMPTY);
+        out[k] = make_int4(n > 4 * k ? code(4 * k) : EMPTY, n > 4 * k + 1 ? code(4 * k + 1) : EMPTY, n > 4 * k + 2 ? code(4 * k + 2) : EMPTY, n > 4 * k + 3 ? code(4 * k + 3) : EMPTY);
+#undef code
+#undef key
+}
+__global__ __launch_bounds__(64) void k_tile_entry(DevScene sc, PassParams pp, int4* __restrict__ table) { tile_entry_body(sc, pp, table); }
+// k_raygen and k_tile_entry as ONE launch: the first entry_blocks blocks find the entry points (one wave each: a chain of dependent
+// node reads per tile, 0.2 ms on its own with most of the chip idle), the others write the primary rays (bound by their stores)
+__global__ __launch_bounds__(256) void k_raygen_entry(DevScene sc, PassParams pp, RayQueue q, float4* __restrict__ radiance, uint32_t* __restrict__ ctl,
+                                                      int4* __restrict__ table, uint32_t entry_blocks) {
+    if (blockIdx.x < entry_blocks) {
+        if (threadIdx.x < 64u) tile_entry_body(sc, pp, table);
+        return;
+    }
+    raygen_body(sc, pp, q, radiance, ctl, entry_blocks);
 }
 
 // ---------------------------------------------------------------- shading
@@ -1993,6 +2020,12 @@ void launch_raygen(const LaunchCfg& cfg, const DevScene& sc, const PassParams& p
                    uint32_t capacity, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, capacity);
+}
+void launch_raygen_entry(const LaunchCfg& cfg, const DevScene& sc, const PassParams& pp, RayQueue q, float4* radiance, uint32_t* ctl, int4* table,
+                         hipStream_t st) {
+    const uint32_t entry_blocks = cdiv((uint64_t)(pp.npix_pad >> 6) * (RT_ENTRY_SUB * RT_ENTRY_SUB), 64);
+    const uint32_t blocks = std::min<uint32_t>(cdiv(pp.n_paths, 256), cfg.n_cu * 16u);
+    hipLaunchKernelGGL(k_raygen_entry, dim3(entry_blocks + blocks), dim3(256), 0, st, sc, pp, q, radiance, ctl, table, entry_blocks);
 }
 void launch_pass_begin(uint32_t* ctl, uint32_t n_paths, hipStream_t st) {
     hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, ctl, n_paths);
