@@ -197,14 +197,15 @@ def test_axis_parallel_rays_do_not_walk_the_tree(ctx):
     assert want["triangle_id"][32, 32] >= 0
     check_hits(got, want, allow_id_mismatch=2)    # rays through shared edges / vertices of the grid
     # a one-pixel-wide image: EVERY ray has d.x == 0 (measured with the shared bound: 98 nodes and
-    # 189 triangles per ray; per axis: 9 and 2)
+    # 189 triangles per ray; per axis: 9 and 2; with the tiles' entry points, whose leaves a ray tests without
+    # a box test of its own: 5.6 and 7.1 -- a pixel of this image spans several triangles)
     for (w, h) in ((1, 65), (65, 1)):
         small_scene(ctx, objs, w, h)
         ctx.stats_reset()
         ctx.render_image(rt.RenderParams("grid:1", depth=1, counters=True, sample_offset=(0.5, 0.5)))
         st = ctx.stats()
         assert st["rays_total"] == 65
-        assert st["nodes_visited"] / st["rays_total"] < 20.0 and st["prims_tested"] / st["rays_total"] < 6.0, \
+        assert st["nodes_visited"] / st["rays_total"] < 20.0 and st["prims_tested"] / st["rays_total"] < 10.0, \
             (st["nodes_visited"] / st["rays_total"], st["prims_tested"] / st["rays_total"])
 
 
