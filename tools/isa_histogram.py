@@ -56,7 +56,7 @@ def classify(op):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_isa_closest_hit"))
-    ap.add_argument("--kernel", default="k_closest_hitILb0ELb1E")   # <COUNT = false, TRIS = true>
+    ap.add_argument("--kernel", default="k_closest_hitILb0ELb1ELb0E")   # <COUNT = false, TRIS = true, GEN = false>
     ap.add_argument("--keep-asm", default=None)
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
@@ -106,8 +106,8 @@ def main():
                 meta[key] = int(l.split(":")[1])
         if ".name:" in l and meta:
             break
-    out = {"kernel": "k_closest_hit<false, true>", "flags": " ".join(flags()), "regions": {}, "meta": meta}
-    txt = ["k_closest_hit<false, true>, gfx950, flags: %s" % out["flags"], "registers: %s" % meta, "",
+    out = {"kernel": "k_closest_hit<false, true, false>", "flags": " ".join(flags()), "regions": {}, "meta": meta}
+    txt = ["k_closest_hit<false, true, false>, gfx950, flags: %s" % out["flags"], "registers: %s" % meta, "",
            "%-10s %-11s %7s %7s %9s %9s" % ("region", "class", "total", "always", "cyc_total", "cyc_alw")]
     for r, h in hist.items():
         reg = {c: e for c, e in sorted(h.items())}
