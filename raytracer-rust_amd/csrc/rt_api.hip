@@ -54,6 +54,8 @@ struct rt_context {
     bool gen_primary = false; // RTAMD_GEN_PRIMARY=1: iteration 0 forms the primary rays itself instead of reading what k_raygen wrote.  Measured and left
                               // off: k_raygen's 0.9 ms per 133 M paths go, but k_closest_hit (+0.65 ms) and k_shade (+0.8 ms) pay more for forming the ray
                               // again than they save in reads (C5 24.75 -> 25.3 ms per 64-spp step, C3 14.8 -> 15.2)
+    bool shade_split = false; // RTAMD_SHADE_SPLIT=1: k_shade in two launches per iteration (CLS).  Measured and left off: bit-identical renders, C5 24.34 -> 24.46 ms
+                              // per 64-spp step, C4 107.7 -> 115.4 -- the triangle code a mixed wave runs for a handful of lanes is not what its rounds wait for
     bool tile_entry = true;   // primary rays enter the BVH at their tile's entry points (k_tile_entry); RTAMD_TILE_ENTRY=0: at the root (A/B, tests)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_prims = 0;
     double bvh_build_ms = 0;
@@ -63,6 +65,7 @@ struct rt_context {
     uint32_t path_capacity = 0; // radiance slots
     RayQueue q[2]{};
     float2* hits = nullptr;    // (t, code) per ray
+    uint32_t* heavy = nullptr; // queue slots of the rays k_shade<.., 1> leaves to k_shade<.., 2> (one per ray of a queue at most)
     float4* radiance = nullptr;
     uint32_t* ctl = nullptr;
     unsigned long long* stats_dev = nullptr;   // CTL_MAX_IT + 1 + N_STAT64 words
@@ -141,6 +144,7 @@ void free_state(rt_context* ctx) {
         ctx->q[k] = RayQueue{};
     }
     (void)hipFree(ctx->hits); ctx->hits = nullptr;
+    (void)hipFree(ctx->heavy); ctx->heavy = nullptr;
     (void)hipFree(ctx->radiance); ctx->radiance = nullptr;
     ctx->capacity = 0; ctx->path_capacity = 0;
 }
@@ -157,6 +161,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].f, (size_t)capacity * sizeof(uint4)));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->heavy, (size_t)capacity * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
         ctx->capacity = capacity;
         ctx->path_capacity = paths;
@@ -203,6 +208,7 @@ int rt_context_create(int device_id, rt_context** out) {
     rt_context* ctx = new rt_context();
     if (const char* e = getenv("RTAMD_TILE_ENTRY")) ctx->tile_entry = atoi(e) != 0;
     if (const char* e = getenv("RTAMD_GEN_PRIMARY")) ctx->gen_primary = atoi(e) != 0;
+    if (const char* e = getenv("RTAMD_SHADE_SPLIT")) ctx->shade_split = atoi(e) != 0;
     if (const char* e = getenv("RTAMD_ANY_HIT")) ctx->any_hit_last = atoi(e) != 0;
     ctx->device = device_id;
     ctx->cfg.n_cu = (uint32_t)prop.multiProcessorCount;
@@ -583,6 +589,7 @@ extern "C" {
 struct WaveState {
     RayQueue q[2];
     float2* hits;
+    uint32_t* heavy;     // NULL: every iteration is shaded in one launch (the no-alloc entry point: the static scratch has no room for the list)
     float4* radiance;
     uint32_t* ctl;
     uint32_t capacity;   // rays per queue
@@ -673,7 +680,7 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
             if (p->max_paths_per_pass || max_paths <= (1u << 20)) return 1;
             max_paths >>= 1;
         }
-        ws.q[0] = ctx->q[0]; ws.q[1] = ctx->q[1]; ws.hits = ctx->hits; ws.radiance = ctx->radiance; ws.ctl = ctx->ctl;
+        ws.q[0] = ctx->q[0]; ws.q[1] = ctx->q[1]; ws.hits = ctx->hits; ws.heavy = ctx->heavy; ws.radiance = ctx->radiance; ws.ctl = ctx->ctl;
         // the capacity of THIS call, not of the (possibly larger) buffers an earlier call left behind: whether rays
         // are dropped must not depend on the context's history
         ws.capacity = (uint32_t)cap64;
@@ -750,7 +757,14 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
                     ctx->events_used++;
                 }
                 if (hits_only) break;
-                launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, gen && it == 0 ? &pp : nullptr, st);
+                // scenes with triangles, the bounces between the first and the last: the hits on triangles are shaded by a launch of
+                // their own (k_shade, CLS)
+                if (ctx->shade_split && sc.n_tris && it > 0 && last == 0 && ws.heavy) {
+                    launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, nullptr, 1, ws.heavy, st);
+                    launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, nullptr, 2, ws.heavy, st);
+                } else {
+                    launch_shade(ctx->cfg, sc, qi, ws.hits, qo, ws.radiance, ws.ctl, (int)it, last, capacity, max_rays, gen && it == 0 ? &pp : nullptr, 0, nullptr, st);
+                }
             }
             if (!hits_only) launch_accumulate(sc, pp, ws.radiance, accum_dev, st);
             launch_stats(ws.ctl, ctx->stats_dev, capacity, st);

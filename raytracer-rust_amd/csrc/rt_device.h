@@ -53,7 +53,8 @@ constexpr int CTL_OVERFLOW = CTL_FETCH + CTL_FETCH_SEGS * CTL_FETCH_STRIDE;
 //   4 refills (waves)             5 rays that re-hit their own triangle (no traversal)  6 lanes with work summed over the steps
 constexpr int CTL_STAT64 = CTL_OVERFLOW + 2;
 constexpr int N_STAT64 = 8;
-constexpr int CTL_WORDS = CTL_STAT64 + 2 * N_STAT64;
+constexpr int CTL_HEAVY = CTL_STAT64 + 2 * N_STAT64;   // [it & 1] rays k_shade<.., 1> left to k_shade<.., 2> (see k_shade, CLS)
+constexpr int CTL_WORDS = CTL_HEAVY + 2;
 static_assert(CTL_STAT64 % 2 == 0, "64-bit counters must be 8-byte aligned");
 
 // Ray queue, structure of arrays of 16-byte words so that every wave-level access

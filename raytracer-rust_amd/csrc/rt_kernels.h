@@ -19,7 +19,7 @@ void launch_tile_entry(const DevScene& sc, const PassParams& pp, int4* table, hi
 void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, float2* hits, uint32_t* ctl, int it, uint32_t capacity,
                         uint32_t max_rays, bool counters, TileEntry entry, bool any_hit, const PassParams* gen, hipStream_t st);   // gen != NULL: iteration 0 forms its rays itself (no k_raygen)
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
-                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, const PassParams* gen, hipStream_t st);
+                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, const PassParams* gen, int cls, uint32_t* heavy, hipStream_t st);   // cls: k_shade's CLS (0: one launch; 1, 2: the two launches of a split iteration)
 void launch_accumulate(const DevScene& sc, const PassParams& pp, const float4* radiance, float* accum, hipStream_t st);
 void launch_resolve(const float* accum, size_t n_values, float inv_spp, uint8_t* rgb8, float* color, hipStream_t st);
 void launch_hit_info(const DevScene& sc, const PassParams& pp, RayQueue q, const float2* hits, const uint32_t* ctl, uint32_t capacity,

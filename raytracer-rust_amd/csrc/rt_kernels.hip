@@ -170,9 +170,6 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #ifndef RT_SHADE_PREFETCH_S
 #define RT_SHADE_PREFETCH_S 1   // the first word of the next round's shading record is gathered behind the slot claim (see k_shade)
 #endif
-#ifndef RT_SHADE_SORT
-#define RT_SHADE_SORT 0   // 1: the rays of a block round are sorted by hit class through LDS (measured: C5 +1.5 %, C4 +2.5 % step time; see k_shade)
-#endif
 #ifndef RT_PRIMARY_REFORDER
 #define RT_PRIMARY_REFORDER 1
 #endif
@@ -853,7 +850,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                                 // (scenes with triangles: the distance only ranks, see sphere_rank32; for a radius-1000 sphere its f32
                                 // discriminant is good to ~3e-4 of a distance of 12, inside the band RT_TIE_EPS hands to k_shade)
                                 const float t = (TRIS && RT_SPHERE_RANK32 > 1) ? sphere_rank32(r0, r1, o, d, src == pi) : sphere_hit64(r0, r1, o, d, src == pi);
-                                if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
+                                if (t > 0.f) consider(tris, tie_k, best, t, tris ? pi | HIT_SPHERE_BIT : pi, __float_as_uint(r2.y));
                             }
                             if (sc.n_leaf_prims && F.x != CHILD_EMPTY_CODE && !(any_hit && best.code != HIT_MISS)) {
                                 const float ooeps = 0x1p-80f;
@@ -1045,7 +1042,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
                     f3 o_ = o, d_ = d;
                     asm volatile("; RTMARK leaf_sphere" : "+v"(o_.x), "+v"(o_.y), "+v"(o_.z), "+v"(d_.x), "+v"(d_.y), "+v"(d_.z));
                     const float t = (TRIS && RT_SPHERE_RANK32) ? sphere_rank32(L0, L1, o_, d_, src == pi) : sphere_hit(L0, L1, o_, d_, src == pi);
-                    if (t > 0.f) consider(tris, tie_k, best, t, tris && RT_SHADE_SORT ? pi | HIT_SPHERE_BIT : pi, gid);
+                    if (t > 0.f) consider(tris, tie_k, best, t, tris ? pi | HIT_SPHERE_BIT : pi, gid);
                 }
                 asm volatile("; RTMARK leaf_end");
                 if (any_hit && best.code != HIT_MISS) { node = STACK_SENTINEL; pend = pcur; }   // a hit: that is all the path's last ray asks
@@ -1345,6 +1342,32 @@ __device__ __forceinline__ uint32_t block_alloc(bool want, uint32_t per_lane, ui
     return slot;
 }
 
+// The same for two kinds of slots at once (k_shade, CLS = 1: a slot of the next queue for a ray that goes on, a slot of the list
+// of rays left to the second launch): one pass through the two barriers, two atomics by one thread.  lds: [34]
+__device__ __forceinline__ uint32_t block_alloc2(bool want, uint32_t* counter, bool want2, uint32_t* counter2, uint32_t& slot2, uint32_t* lds) {
+    const uint64_t m = __ballot(want), m2 = __ballot(want2);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+    if (lane == 0) { lds[wave] = (uint32_t)__popcll(m); lds[17 + wave] = (uint32_t)__popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0, total2 = 0;
+        for (int w = 0; w < SHADE_THREADS / 64; ++w) {
+            const uint32_t c = lds[w], c2 = lds[17 + w];
+            lds[w] = total; total += c;
+            lds[17 + w] = total2; total2 += c2;
+        }
+        lds[16] = total ? atomicAdd(counter, total) : 0u;
+        lds[33] = total2 ? atomicAdd(counter2, total2) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = lds[16] + lds[wave] + rank;
+    slot2 = lds[33] + lds[17 + wave] + rank2;
+    __syncthreads();   // lds is reused by the next call
+    return slot;
+}
+
 // The reference's distance to primitive / plane `c` along the f64 ray, or +inf where it reports no hit
 // (intersections.rs:42-67, 84-93, 153-168), operation by operation.
 __device__ __forceinline__ double ref_t64(const DevScene& sc, uint32_t c, d3 o64, d3 d64) {
@@ -1395,36 +1418,35 @@ __device__ __forceinline__ uint32_t resolve_tie(const DevScene& sc, uint32_t cod
 // scattered ray is worthless (it would return black at depth == max_depth) and only the
 // light-sampling branch of raytrace.rs:74-87 can continue the path.  last == 2: the caller runs no
 // further generation (rt_render_params.max_shadow_generations), so nothing is emitted.
-template <bool TRIS, int PRIMARY>   // PRIMARY: iteration 0; 1: the queue holds 16-byte primary rays (k_raygen), 2: no queue, the ray is formed here (see k_closest_hit, GEN)
+// CLS (scenes with triangles, the bounces between the first and the last): the rays of an iteration shaded in TWO launches.  A hit
+// on a triangle costs two evaluations of the reference's f64 determinants (hit point, re-hit test), a hit on a sphere the f64
+// quadratic, a miss next to nothing, and a wave pays for every kind one of its 64 lanes holds: after the first bounce one ray in
+// eight of C5 hits a triangle, so nearly every wave ran the triangle code for a handful of lanes.  CLS = 1 shades everything but the
+// hits on triangles and the hits with a runner-up to decide (resolve_tie), whose queue slots it appends to a list (one more count
+// in the block's slot claim, no further barrier); CLS = 2 runs over that list with waves that hold nothing else.  The rays a path
+// emits, its random numbers and its radiance word do not depend on the launch that shades it: renders are bit-identical to CLS = 0.
+template <bool TRIS, int PRIMARY, int CLS>   // PRIMARY: iteration 0; 1: the queue holds 16-byte primary rays (k_raygen), 2: no queue, the ray is formed here (see k_closest_hit, GEN)
 __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_SHADE_MINWAVES) void k_shade(DevScene sc, RayQueue qi, const float2* __restrict__ hits, RayQueue qo,
                                                float4* __restrict__ radiance, uint32_t* __restrict__ ctl, int it, int last,
-                                               uint32_t capacity, PassParams pp) {
+                                               uint32_t capacity, PassParams pp, uint32_t* __restrict__ heavy) {
     constexpr bool GEN = PRIMARY == 2;
-    __shared__ uint32_t lds_alloc[17];
-    // RT_SHADE_SORT (off: measured and dropped, kept as a variant).  The rays of a block round sorted by what they hit before they
-    // are shaded (scenes with triangles): a triangle hit costs two evaluations of the reference's f64 determinants (hit point,
-    // re-hit test), a sphere hit the f64 quadratic, a plane hit or a miss next to nothing, and a wave pays for every kind one of
-    // its 64 lanes holds (VALU lane utilisation of this kernel on C5: 0.49).  A counting sort over the block's 1024 rays by class
-    // (the hit code names it: HIT_PLANE_BIT, HIT_SPHERE_BIT) through LDS makes all but three waves of a block homogeneous; the
-    // queue words travel with the ray (56 bytes each), the slot it came from in lds_i.  Correct (whole GPU suite green), and
-    // slower: C5 28.0 -> 28.4 ms per step, C4 120.7 -> 123.8 (same-box A/B): the kernel waits on memory, not on its VALU work,
-    // and two more barriers and 112 KB of LDS traffic per round cost more than the divergence they remove.
-    constexpr bool SORT = TRIS && RT_SHADE_SORT;
-    constexpr uint32_t SN = SORT ? SHADE_THREADS : 1, SN2 = SORT && !PRIMARY ? SHADE_THREADS : 1;
-    __shared__ float4 lds_a[SN], lds_b[SN2], lds_c[SN2];
-    __shared__ float2 lds_h[SN];
-    __shared__ uint16_t lds_i[SN];
-    __shared__ uint32_t lds_cnt[2][64];   // [round parity][class * 16 + wave]
+    static_assert(CLS == 0 || (TRIS && PRIMARY == 0), "the two-launch form exists for the later bounces of scenes with triangles");
+    __shared__ uint32_t lds_alloc[34];
     uint32_t parity = 0;
-    const uint32_t n = min(ctl[CTL_QCOUNT + it], capacity);
+    // CLS = 2: the rays are those of the list CLS = 1 made (two counters taking turns: this launch clears the one the next iteration's list will count in)
+    const uint32_t n = CLS == 2 ? min(ctl[CTL_HEAVY + (it & 1)], capacity) : min(ctl[CTL_QCOUNT + it], capacity);
+    if (CLS == 2 && blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_HEAVY + ((it + 1) & 1)] = 0u;
     const uint32_t n_pad = (n + (SHADE_THREADS - 1)) & ~(uint32_t)(SHADE_THREADS - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
+    (void)parity;
     // The ray and hit words of a round are loaded one round ahead (RT_SHADE_PREFETCH), right before the round's slot claim:
     // a round is a chain of dependent waits (queue words, shading record, the claim's atomic between two barriers) that all
     // 16 waves of the block walk in step, and this takes the first link off it.
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA, nC = nA;
     float2 nH = make_float2(0.f, 0.f);
+    uint32_t nMy = 0;   // CLS = 2: the queue slot of the next round's ray (its words are gathered at the top of the round)
     auto load_round = [&](uint32_t j) {
+        if (CLS == 2) { nMy = heavy[j]; return; }
         if (!GEN) nA = ld_stream(&qi.a[j]);
         nH = ld_stream(&hits[j]);
         if (!PRIMARY) { nB = ld_stream(&qi.b[j]); nC = ld_stream(&qi.c[j]); }
@@ -1453,40 +1475,12 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         float4 A = nA, B = nB, C = nC;
         float2 H = nH;
         uint32_t my = i;                                  // the queue slot of the ray this thread shades
-        if (!(i < n)) H = make_float2(__uint_as_float(HIT_MISS), __uint_as_float(HIT_INVALID));
-        if (SORT) {
-            const uint32_t raw = __float_as_uint(H.y), aux = __float_as_uint(H.x);
-            // 0: triangle, or two candidates to decide between (resolve_tie); 1: sphere; 2: plane; 3: miss, padding slot
-            const uint32_t cls = raw == HIT_INVALID ? 3u : aux != HIT_MISS ? 0u : raw == HIT_MISS ? 3u : (raw & HIT_PLANE_BIT) ? 2u : (raw & HIT_SPHERE_BIT) ? 1u : 0u;
-            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
-            const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
-            if (lane < 4u) lds_cnt[parity][lane * 16u + wave] = lane == 0u ? c0 : lane == 1u ? c1 : lane == 2u ? c2 : 64u - c0 - c1 - c2;
-            __syncthreads();
-            // every wave scans the 64 counts itself (class-major, so the running sum is the sorted position)
-            const uint32_t cnt = lds_cnt[parity][lane];
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(incl, off);
-                if (lane >= (uint32_t)off) incl += v;
-            }
-            parity ^= 1u;
-            // a block of one class (all sky, all ground) is left as it is
-            const uint32_t t0 = __shfl(incl, 15), t1 = __shfl(incl, 31), t2 = __shfl(incl, 47);
-            const bool mixed = !(t0 == SHADE_THREADS || t1 - t0 == SHADE_THREADS || t2 - t1 == SHADE_THREADS || t2 == 0u);
-            if (mixed) {
-                const uint32_t base = __shfl(incl - cnt, (int)(cls * 16u + wave));
-                const uint64_t mine = cls == 0u ? m0 : cls == 1u ? m1 : cls == 2u ? m2 : ~(m0 | m1 | m2);
-                const uint32_t dest = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-                lds_a[dest] = A; lds_h[dest] = H; lds_i[dest] = (uint16_t)threadIdx.x;
-                if (!PRIMARY) { lds_b[dest] = B; lds_c[dest] = C; }
-                __syncthreads();
-                A = lds_a[threadIdx.x]; H = lds_h[threadIdx.x];
-                if (!PRIMARY) { B = lds_b[threadIdx.x]; C = lds_c[threadIdx.x]; }
-                my = i - threadIdx.x + lds_i[threadIdx.x];
-            }
+        if (CLS == 2 && i < n) {
+            my = nMy;
+            A = ld_stream(&qi.a[my]); B = ld_stream(&qi.b[my]); C = ld_stream(&qi.c[my]); H = ld_stream(&hits[my]);
         }
+        if (!(i < n)) H = make_float2(__uint_as_float(HIT_MISS), __uint_as_float(HIT_INVALID));
+        bool defer = false;      // CLS = 1: this ray is left to the second launch
         if (__float_as_uint(H.y) != HIT_INVALID) {
             f3 o, d;
             uint32_t src = SRC_NONE;
@@ -1513,8 +1507,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 rng = __float_as_uint(C.w);
             }
             code = strip_hit(__float_as_uint(H.y));
-            const bool sphere_hit_ = TRIS ? (__float_as_uint(H.y) & HIT_SPHERE_BIT) != 0u && code < SRC_SPECIAL && !(code & HIT_PLANE_BIT) : true;
-            (void)sphere_hit_;
+            if (CLS == 1) {
+                const uint32_t raw = __float_as_uint(H.y), aux = __float_as_uint(H.x);
+                defer = (aux != HIT_MISS && strip_hit(aux) != code) || (code < SRC_SPECIAL && !(code & HIT_PLANE_BIT) && !(raw & HIT_SPHERE_BIT));
+                if (defer) code = HIT_INVALID;   // (nothing below touches it: no radiance word, no ray)
+            }
             float u = 0.f, v = 0.f;
             // The ray as the f64 arithmetic below sees it: the exact eye for a primary ray, the carried f64 origin for a ray
             // that left a triangle, a plane or a sphere (SRC_E_BIT), a dithered f32 origin otherwise; the carried f64
@@ -1558,7 +1555,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 // the hit's records, so that they do not wait for the queue word of the f64 ray.)
                 // The same for a candidate at t ~ 0 (AUX_NEAR_BIT): the hit may then have been a miss so far.
                 const uint32_t code2 = __float_as_uint(H.x);
-                if (RT_TIE_SHADE && code != HIT_INVALID && code2 != HIT_MISS && strip_hit(code2) != code) {
+                if (RT_TIE_SHADE && CLS != 1 && code != HIT_INVALID && code2 != HIT_MISS && strip_hit(code2) != code) {   // (CLS = 1 has left these to the second launch)
                     d3 o64t;
                     ray64(o64t, true);
                     code = resolve_tie(sc, code, code2, o64t, d64, near_tri);
@@ -1605,7 +1602,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const float4 S = (RT_SHADE_PREFETCH_S && nS_code == code) ? nS : rec[0];
                     sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
-                    if (TRIS && !(sw & SMETA_SPHERE)) {
+                    if (TRIS && CLS != 1 && !(sw & SMETA_SPHERE)) {   // (CLS = 1: every primitive it shades is a sphere)
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
                         // t, the hit point and the barycentrics with the reference's own f64 sequence on its own f64
                         // operands (see tri_hit_ref).  The ray enters it as f64: the exact eye for a primary ray, the
@@ -1671,7 +1668,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         return mkd(P64[3], P64[4], P64[5]);
                     }
                     const double2* __restrict__ r64 = reinterpret_cast<const double2*>(sc.smeta + SMETA_WORDS * (size_t)code + 1);
-                    if (!(sw & SMETA_SPHERE)) {                                            // intersections.rs:169
+                    if (CLS != 1 && !(sw & SMETA_SPHERE)) {                                // intersections.rs:169
                         const double2 w1 = r64[1], w2 = r64[2], w3 = r64[3], w4 = r64[4];
                         return normalized_ref(cross_ref(mkd(w1.y, w2.x, w2.y), mkd(w3.x, w3.y, w4.x)));
                     }
@@ -1799,7 +1796,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             other_out = HIT_MISS;
             const uint32_t flags = has_p64 ? (SRC_E_BIT | (exact ? SRC_D_BIT : 0u)) : 0u;
             src_out = code | flags;
-            if (!TRIS || (!on_tri && near_tri == HIT_MISS)) return false;
+            if (!TRIS || CLS == 1 || (!on_tri && near_tri == HIT_MISS)) return false;   // (CLS = 1 shades no hit on a triangle and no hit with a coplanar partner)
             if (!on_tri) src_out = near_tri | flags;
             uint32_t dh = pcg_hash(rng_out ^ 0x68E31DA4u);
             const d3 nd64 = exact ? mkd(join64(dir_out.x, d_lo_x), join64(dir_out.y, d_lo_y), join64(dir_out.z, d_lo_z)) : dither64(dir_out, dh);
@@ -1835,8 +1832,15 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
         }
         if (!last) {
             // (ordering the block's slots by the octant of the new direction was measured: no gain)
-            const uint32_t slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
-            if (RT_SHADE_PREFETCH && RT_SHADE_PREFETCH_S) {
+            uint32_t slot;
+            if (CLS == 1) {
+                uint32_t hslot = 0;
+                slot = block_alloc2(emit, &ctl[CTL_QCOUNT + it + 1], defer, &ctl[CTL_HEAVY + (it & 1)], hslot, lds_alloc);
+                if (defer) heavy[hslot] = my;
+            } else {
+                slot = block_alloc(emit, 1u, &ctl[CTL_QCOUNT + it + 1], lds_alloc);
+            }
+            if (RT_SHADE_PREFETCH && RT_SHADE_PREFETCH_S && CLS != 2) {
                 const uint32_t c = strip_hit(__float_as_uint(nH.y));
                 nS_code = ((uint64_t)i + stride < n && c < SRC_SPECIAL && !(c & HIT_PLANE_BIT)) ? c : HIT_MISS;
                 if (nS_code != HIT_MISS) nS = sc.smeta[SMETA_WORDS * (size_t)c];
@@ -2054,18 +2058,20 @@ void launch_closest_hit(const LaunchCfg& cfg, const DevScene& sc, RayQueue q, fl
 #undef RT_HIT_LAUNCH
 }
 void launch_shade(const LaunchCfg& cfg, const DevScene& sc, RayQueue qi, const float2* hits, RayQueue qo, float4* radiance,
-                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, const PassParams* gen, hipStream_t st) {
+                  uint32_t* ctl, int it, int last, uint32_t capacity, uint32_t max_rays, const PassParams* gen, int cls, uint32_t* heavy, hipStream_t st) {
     uint32_t blocks = std::min<uint32_t>(cfg.n_cu * RT_SHADE_GRID_MUL, std::max<uint32_t>(1, cdiv(max_rays, SHADE_THREADS)));
     const dim3 g(blocks), b(SHADE_THREADS);
     PassParams pp0{};
     const PassParams& pp = gen ? *gen : pp0;
-#define RT_SHADE_LAUNCH(T, P) hipLaunchKernelGGL((k_shade<T, P>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity, pp)
+#define RT_SHADE_LAUNCH(T, P, C) hipLaunchKernelGGL((k_shade<T, P, C>), g, b, 0, st, sc, qi, hits, qo, radiance, ctl, it, last, capacity, pp, heavy)
     if (sc.n_tris) {
-        if (it == 0) { if (gen) RT_SHADE_LAUNCH(true, 2); else RT_SHADE_LAUNCH(true, 1); }
-        else RT_SHADE_LAUNCH(true, 0);
+        if (it == 0) { if (gen) RT_SHADE_LAUNCH(true, 2, 0); else RT_SHADE_LAUNCH(true, 1, 0); }
+        else if (cls == 1) RT_SHADE_LAUNCH(true, 0, 1);
+        else if (cls == 2) RT_SHADE_LAUNCH(true, 0, 2);
+        else RT_SHADE_LAUNCH(true, 0, 0);
     } else {
-        if (it == 0) { if (gen) RT_SHADE_LAUNCH(false, 2); else RT_SHADE_LAUNCH(false, 1); }
-        else RT_SHADE_LAUNCH(false, 0);
+        if (it == 0) { if (gen) RT_SHADE_LAUNCH(false, 2, 0); else RT_SHADE_LAUNCH(false, 1, 0); }
+        else RT_SHADE_LAUNCH(false, 0, 0);
     }
 #undef RT_SHADE_LAUNCH
 }

@@ -422,3 +422,40 @@ def test_primary_rays_formed_in_iteration_0_change_nothing():
                     assert differ < 2e-4 and abs(a.mean(dtype=np.float64) - b.mean(dtype=np.float64)) <= 1e-5 * a.mean(dtype=np.float64)
     finally:
         off.close(); on.close()
+
+
+def test_shading_in_two_launches_changes_nothing():
+    """k_shade, CLS (RTAMD_SHADE_SPLIT=1; off by default: measured slower): in scenes with triangles the bounces between the first and the last are shaded in two launches -- everything
+    but the hits on triangles and the hits with a runner-up to decide, then those.  The rays a path emits, its random numbers and
+    its radiance word do not depend on the launch that shades it: renders without lights are identical value by value with one
+    launch per iteration (the default) -- C4, C5, several passes, a tile split, and a scene of coplanar surfaces (two glass
+    boxes standing exactly on the ground plane: runner-ups, re-hits with a coplanar partner, exact directions)."""
+    from test_gpu_parity import _box, _mesh
+    os.environ["RTAMD_SHADE_SPLIT"] = "1"
+    try:
+        on = rt.Context(0)
+    finally:
+        del os.environ["RTAMD_SHADE_SPLIT"]
+    off = rt.Context(0)
+    try:
+        gy = -0.4371
+        glass = lambda ior, tint: dict(type="Dieletrics", tint=tint, refraction_index=ior)
+        boxes = dict(width=96, height=72, background=[0.7, 0.8, 0.9], camera=dict(eye=[0.3, 3.1, 4.9], look_at=[0.0, -0.2, -0.3], up=[0.0, 1.0, 0.0], fovy=35.0),
+                     objects=[_mesh(_box([-1.31, gy, -1.07], [0.42, 0.38, 0.51]), glass(1.31, [0.9, 0.8, 0.7])),
+                              _mesh(_box([-0.37, gy, -0.63], [1.23, 0.71, 0.93]), glass(1.52, [0.7, 0.9, 0.8])),
+                              _mesh(_box([0.5, 0.71, -0.5], [1.0, 1.25, 0.25]), dict(type="Metal", albedo=[0.9, 0.9, 0.9], fuzziness=0.0)),
+                              dict(type="Sphere", center=[-0.4, 0.9, 0.1], radius=0.5, material=dict(type="Lambertian", albedo=[0.5, 0.3, 0.2])),
+                              dict(type="Plane", center=[0.0, gy, 0.0], normal=[0.0, 1.0, 0.0], material=dict(type="Lambertian", albedo=[0.6, 0.6, 0.6]))])
+        for name, sc in (("boxes", boxes), ("c4", scenegen.scene_c4(387, 213, 120, 60)), ("c5", scenegen.scene_c5(645, 363, 200, 100))):
+            scene = rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"])
+            off.upload(scene); on.upload(scene)
+            for kw in (dict(ssaa="jitter:4", depth=6), dict(ssaa="jitter:3", depth=3, max_paths_per_pass=64 * 500), dict(ssaa="jitter:2", depth=8, tile_index=1, tile_count=3),
+                       dict(ssaa="jitter:2", depth=2)):
+                p = rt.RenderParams(kw.pop("ssaa"), seed=17, **kw)
+                off.stats_reset(); on.stats_reset()
+                a, _ = off.render_image(p)
+                b, _ = on.render_image(p)
+                assert np.array_equal(a, b), "%s %s: renders differ in %d values" % (name, kw, (a != b).sum())
+                assert off.stats()["rays_per_iteration"] == on.stats()["rays_per_iteration"]
+    finally:
+        off.close(); on.close()
