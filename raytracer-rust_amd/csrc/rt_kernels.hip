@@ -167,6 +167,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
     return x < sc.width && row < sc.height;
 }
 
+#ifndef RT_SHADE_EARLY_MAT
+#define RT_SHADE_EARLY_MAT 1
+#endif
 #ifndef RT_SHADE_PREFETCH_S
 #define RT_SHADE_PREFETCH_S 1   // the first word of the next round's shading record is gathered behind the slot claim (see k_shade)
 #endif
@@ -1573,11 +1576,15 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 float t = H.x;
                 f3 nrm;
                 int mat;
+                // (the material words are asked for as soon as the material is known, ahead of the f64 hit-point arithmetic: behind it,
+                // where they are used, their round trip was one more link of the round's chain of waits)
+                float4 M0, M1;
                 if (code & HIT_PLANE_BIT) {
                     const uint32_t pl = code & ~HIT_PLANE_BIT;
                     const float4 P1 = sc.planes[2 * pl + 1];
                     nrm = mk(P1.x, P1.y, P1.z);                                            // intersections.rs:96 (as given)
                     mat = __float_as_int(P1.w);
+                    if (RT_SHADE_EARLY_MAT) { M0 = sc.materials[2 * mat]; M1 = sc.materials[2 * mat + 1]; }
                     if (TRIS) {
                         // intersections.rs:84-95 in f64 on the reference's operands: the point a ray leaves a plane from is
                         // ON it to an ulp of f64 (e.g. y = -0.6 exactly for 98.7 % of the rays, one ulp off for the rest), and
@@ -1602,6 +1609,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                     const float4 S = (RT_SHADE_PREFETCH_S && nS_code == code) ? nS : rec[0];
                     sw = __float_as_uint(S.w);
                     mat = (int)(sw & ~SMETA_FLAGS);
+                    if (RT_SHADE_EARLY_MAT) { M0 = sc.materials[2 * mat]; M1 = sc.materials[2 * mat + 1]; }
                     if (TRIS && CLS != 1 && !(sw & SMETA_SPHERE)) {   // (CLS = 1: every primitive it shades is a sphere)
                         nrm = mk(S.x, S.y, S.z);                                           // intersections.rs:169, see smeta
                         // t, the hit point and the barycentrics with the reference's own f64 sequence on its own f64
@@ -1657,7 +1665,7 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                         }
                     }
                 }
-                const float4 M0 = sc.materials[2 * mat], M1 = sc.materials[2 * mat + 1];
+                if (!RT_SHADE_EARLY_MAT) { M0 = sc.materials[2 * mat]; M1 = sc.materials[2 * mat + 1]; }
                 const int mtype = __float_as_int(M1.x);
                 // intersection_info.normal as the reference has it, in f64 (only the specular materials ask for it; the
                 // records are read again rather than kept in registers)
