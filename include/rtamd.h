@@ -113,11 +113,11 @@ typedef struct rt_render_params {
     uint32_t sample_end;     /* (anti_aliasing.rs:96-100); end = 0 means N*N             */
     uint32_t tile_index;     /* 8x8-pixel tiles are dealt round-robin: this call renders */
     uint32_t tile_count;     /* tiles t with t % tile_count == tile_index; 0 means 1     */
-    uint32_t max_paths_per_pass;     /* 0 = default (128 Mi paths; the wavefront state is   */
-                                     /* 16 + 168 * max(1, n_lights) bytes per path: 184 B,  */
-                                     /* 24.7 GB for the default pass; fewer paths with more */
-                                     /* than 4 lights: a queue holds one ray per light and  */
-                                     /* path)                                               */
+    uint32_t max_paths_per_pass;     /* 0 = default: as many paths as fit in 70 % of the    */
+                                     /* device memory free at the call, at most 2^30 (the   */
+                                     /* wavefront state is 16 + 168 * max(1, n_lights)      */
+                                     /* bytes per path: 184 B, 197 GB for 2^30 paths; few,  */
+                                     /* large launches are faster: DESIGN.md section 3)     */
     uint32_t max_shadow_generations; /* cap of the shadow-ray branching process          */
                                      /* (raytrace.rs:78-85 recursion); 0 = default 16    */
     uint32_t flags;          /* rt_render_flags                                          */

@@ -161,7 +161,7 @@ int ensure_state(rt_context* ctx, uint32_t paths, uint32_t capacity) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->q[k].f, (size_t)capacity * sizeof(uint4)));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->hits, (size_t)capacity * sizeof(float2)));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->heavy, (size_t)capacity * sizeof(uint32_t)));
+        if (ctx->shade_split) HIP_TRY(ctx, hipMalloc((void**)&ctx->heavy, (size_t)capacity * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->radiance, (size_t)paths * sizeof(float4)));
         ctx->capacity = capacity;
         ctx->path_capacity = paths;
@@ -658,12 +658,31 @@ static int render_accumulate_impl(rt_context* ctx, const rt_render_params* p, fl
         ws.radiance = reinterpret_cast<float4*>(carve((size_t)paths * sizeof(float4)));
         ws.capacity = (uint32_t)cap;
     } else {
-        // few, large launches: 16 Mi-path passes were 15 % slower than one of 128 Mi.  Scenes with many lights need
-        // one queue slot per light and path, so their default pass is smaller.
-        uint32_t max_paths = p->max_paths_per_pass ? p->max_paths_per_pass : std::max<uint32_t>(1u << 20, (1u << 27) / std::max(1u, per_path / 4u));
+        // Few, large launches: fill and drain of the persistent waves and the tail of every launch are paid per launch, so a pass is
+        // as large as the GPU's memory allows -- same-box, C5's 512-spp step of 1.06 G paths: 192.7 ms in eight passes of 128 Mi paths,
+        // 188.2 in four, 184.9 in two, 178.2 in ONE pass (197 GB of wavefront state out of 288 GB); C4's 4K frame 107.7 -> 99.2 ms in one
+        // pass instead of four.  The default pass is therefore what fits in 70 % of the device memory that is free now (plus what this
+        // context already holds), at most 2^30 paths and 2^31 queue slots (32-bit slot arithmetic); scenes with many lights need one
+        // queue slot per light and path.
+        uint32_t max_paths = p->max_paths_per_pass;
+        if (!max_paths) {
+            const uint64_t call_paths = (uint64_t)n_local * 64u * (se - sb);
+            const uint64_t hard = std::min<uint64_t>(1ull << 30, (1ull << 31) / per_path);
+            if (std::min(call_paths, hard) <= ctx->path_capacity && std::min(call_paths, hard) * per_path <= ctx->capacity) {
+                max_paths = (uint32_t)std::min<uint64_t>(hard, ctx->path_capacity);     // what the context holds already is enough: no query
+            } else {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = (size_t)64 << 30; (void)hipGetLastError(); }
+                const double per_slot = 6.0 * sizeof(float4) + 4.0 * sizeof(uint4) + sizeof(float2) + (ctx->shade_split ? sizeof(uint32_t) : 0u);
+                const double held = (double)ctx->capacity * per_slot + (double)ctx->path_capacity * sizeof(float4);
+                const double budget = 0.7 * ((double)free_b + held);
+                const double fit = budget / (per_slot * per_path + sizeof(float4));
+                max_paths = (uint32_t)std::min<double>((double)hard, std::max<double>((double)(1u << 20), fit));
+            }
+        }
         max_paths = std::max<uint32_t>(64, max_paths & ~63u);
         // tiles per pass / samples per pass.  With the default pass size a device that cannot hold the
-        // queues (16 + 168 * max(1, lights) bytes per path: 184 B, 24.7 GB for the default pass) gets smaller passes instead of an error.
+        // queues after all (16 + 168 * max(1, lights) bytes per path: 184 B) gets smaller passes instead of an error.
         uint64_t cap64;
         for (;;) {
             tiles_pass = (uint32_t)std::min<uint64_t>(n_local, max_paths / 64);
