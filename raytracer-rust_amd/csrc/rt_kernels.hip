@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, RT_HIT_MIN_WAVES) void k_closest_hit(DevScene 
     // be small: with one cursor and ranges of 256 the waves finished up to a range apart (4.4 of 6
     // waves per SIMD resident on average over a launch).
     const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t chunk = min(RT_CHUNK_MAX, max(64u, (n / (total_waves * RT_CHUNK_DIV)) & ~63u));   // 128 at 9 M rays, 256 from 17 M on (64..1088 measured)
+    const uint32_t chunk = min(n >= (1u << 28) ? 2u * RT_CHUNK_MAX : RT_CHUNK_MAX, max(64u, (n / (total_waves * RT_CHUNK_DIV)) & ~63u));   // 128 at 9 M rays, 256 from 17 M on (64..1088 measured), 512 from 268 M on (1 G rays: -0.8 %)
     const uint32_t seg_len = ((n + CTL_FETCH_SEGS - 1) / CTL_FETCH_SEGS + 63u) & ~63u;
     uint32_t seg = blockIdx.x % CTL_FETCH_SEGS, segs_left = CTL_FETCH_SEGS;
     // wave-uniform range state
