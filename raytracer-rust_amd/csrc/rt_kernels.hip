@@ -618,6 +618,9 @@ constexpr int32_t STACK_SENTINEL = 0x7FFFFFFF;   // bottom of every traversal st
 #ifndef RT_ENTRY_SUB
 #define RT_ENTRY_SUB 1   // entry points per SUB x SUB part of a tile (1: the 8x8 tile, 2: its 4x4 quarters, 4: 2x2 pixels)
 #endif
+#ifndef RT_ENTRY_PRIMS
+#define RT_ENTRY_PRIMS 1
+#endif
 #ifndef RT_ENTRY_NEAREST
 #define RT_ENTRY_NEAREST 1
 #endif
@@ -1248,6 +1251,46 @@ __device__ __forceinline__ void tile_entry_body(const DevScene& sc, const PassPa
             fin |= 1u << i;
         }
     }
+#if RT_ENTRY_PRIMS
+    // The leaves of the frontier, primitive by primitive: a ray that starts at a leaf tests every primitive of it without a box test of
+    // its own, so a primitive the pyramid cannot reach -- a sphere wholly beyond one of the side planes or farther than the farthest
+    // possible hit, a triangle with all three vertices beyond one side plane -- is taken out here (a leaf of two becomes a leaf of one:
+    // the leaf code (first << 3) | (count - 1) names any run of the leaf-ordered primitives).
+    for (int k = 0; k < n;) {
+        const int32_t c = code(k);
+        if (c >= 0) { ++k; continue; }
+        const uint32_t lc = (uint32_t)~c, first = lc >> 3, cnt = (lc & 7u) + 1u;
+        uint32_t keep = 0u;
+        for (uint32_t j = 0; j < cnt && j < 8u; ++j) {
+            const float4* __restrict__ R = sc.prims + 3 * (size_t)(first + j);
+            const float4 r0 = R[0], r1 = R[1], r2 = R[2];
+            bool out = false;
+            if (__float_as_uint(r2.z) == PRIM_TRIANGLE) {
+                const d3 A = mkd((double)r0.x - eye.x, (double)r0.y - eye.y, (double)r0.z - eye.z);
+                const d3 B = mkd(A.x + (double)r0.w, A.y + (double)r1.x, A.z + (double)r1.y), C = mkd(A.x + (double)r1.z, A.y + (double)r1.w, A.z + (double)r2.x);
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) out = out || (dotd(pn[pl], A) < 0.0 && dotd(pn[pl], B) < 0.0 && dotd(pn[pl], C) < 0.0);
+            } else {
+                const double2* __restrict__ S = reinterpret_cast<const double2*>(R);
+                const double2 s0 = S[0], s1 = S[1];
+                const d3 cc = mkd(s0.x - eye.x, s0.y - eye.y, s1.x - eye.z);
+                const double rad = fabs(s1.y) * (1.0 + 1e-6);
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) out = out || dotd(pn[pl], cc) < -rad * sqrt(dotd(pn[pl], pn[pl]));
+                const double dc = sqrt(dotd(cc, cc)) - rad;
+                out = out || (dc > 0.0 && dc * dc > tmax2);
+            }
+            if (!out) keep |= 1u << j;
+        }
+        if (keep == 0u) {                    // nothing of the leaf can be hit: the entry goes (the last one takes its place)
+            n--;
+            code(k) = code(n); key(k) = key(n);
+            continue;
+        }
+        if (cnt == 2u && keep != 3u) code(k) = (int32_t)~(((first + (keep >> 1)) << 3) | 0u);   // one of two stays
+        ++k;
+    }
+#endif
     // nearest first
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b) {
