@@ -345,6 +345,35 @@ def test_tile_entry_points_change_nothing():
                 acc_a, _ = off.render_image(p)
                 acc_b, _ = on.render_image(p)
                 assert np.array_equal(acc_a, acc_b), "%s: renders differ in %d values" % (name, (acc_a != acc_b).sum())
+        # corner cases of the pyramid / box test and of the distance bound: the eye inside a big sphere (no bound from it), a plane
+        # behind the eye and one in front, a very wide field of view (tiles that span tens of degrees), a one-tile image, sample
+        # offsets far outside the pixel (the hit-id gate allows any offset)
+        from test_gpu_parity import _box, _mesh
+        lam = lambda c: dict(type="Lambertian", albedo=c)
+        inside = [dict(type="Sphere", center=[0.2, 0.1, 0.3], radius=60.0, material=lam([0.5, 0.5, 0.5])), _mesh(_box([-1.0, -1.0, -6.0], [1.0, 0.5, -4.0]), lam([0.6, 0.2, 0.2]))] + \
+                 [dict(type="Sphere", center=[1.7 * np.cos(k), 0.8 * np.sin(2.0 * k), -5.0 + 1.5 * np.sin(k)], radius=0.35, material=lam([0.2, 0.6, 0.3])) for k in range(12)]
+        planes = [dict(type="Plane", center=[0.0, 0.0, 3.0], normal=[0.0, 0.0, -1.0], material=lam([0.3, 0.3, 0.3])),
+                  dict(type="Plane", center=[0.0, -1.2, 0.0], normal=[0.0, 1.0, 0.0], material=lam([0.4, 0.4, 0.4])),
+                  _mesh(_box([-0.8, -1.2, -5.0], [0.6, 0.3, -3.5]), lam([0.6, 0.6, 0.2])), _mesh(_box([0.9, -1.2, -9.0], [2.1, 1.0, -7.5]), lam([0.2, 0.2, 0.7])),
+                  dict(type="Sphere", center=[-1.5, -0.7, -4.0], radius=0.5, material=lam([0.7, 0.3, 0.3]))]
+        cases = [("eye inside a big sphere", inside, dict(eye=[0.0, 0.0, 0.0], look_at=[0.0, 0.0, -5.0], up=[0.0, 1.0, 0.0], fovy=50.0), 67, 45),
+                 ("planes behind and below", planes, dict(eye=[0.0, 0.0, 0.0], look_at=[0.0, -0.2, -5.0], up=[0.0, 1.0, 0.0], fovy=60.0), 61, 37),
+                 ("wide field of view", planes, dict(eye=[0.0, 0.0, 0.0], look_at=[0.0, -0.2, -5.0], up=[0.0, 1.0, 0.0], fovy=170.0), 17, 9),
+                 ("one tile", inside, dict(eye=[0.0, 0.0, 0.0], look_at=[0.3, 0.1, -5.0], up=[0.0, 1.0, 0.0], fovy=35.0), 5, 3)]
+        for name, objs, cam, w, h in cases:
+            scene = rt.Scene.from_objects(w, h, [0.5, 0.6, 0.7], cam, objs)
+            off.upload(scene); on.upload(scene)
+            for dx, dy in ((0.5, 0.5), (0.0, 0.999), (-3.5, 7.25)):
+                a, b = off.primary_hits(dx, dy), on.primary_hits(dx, dy)
+                for k in ("object_id", "triangle_id", "t", "normal"):
+                    assert np.array_equal(a[k], b[k]), "%s: %s differs at offset (%g, %g) in %d pixels" % (name, k, dx, dy, (a[k] != b[k]).sum())
+                assert (dx, dy) != (0.5, 0.5) or (a["object_id"] >= 0).any(), name
+            p = rt.RenderParams("jitter:3", depth=3, seed=5)
+            acc_a, _ = off.render_image(p)
+            acc_b, _ = on.render_image(p)
+            assert np.array_equal(acc_a, acc_b), "%s: renders differ in %d values" % (name, (acc_a != acc_b).sum())
+        scene = scenes[-1][1]
+        off.upload(scene); on.upload(scene)
         # what the entry points save: node visits of the primary rays
         on.stats_reset(); off.stats_reset()
         p = rt.RenderParams("jitter:2", depth=1, seed=5, counters=True)
