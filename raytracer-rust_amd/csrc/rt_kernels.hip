@@ -179,6 +179,9 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #ifndef RT_SPHERE_E
 #define RT_SPHERE_E 0
 #endif
+#ifndef RT_SPHERE_OWN
+#define RT_SPHERE_OWN 1   // ... except by a ray that starts on the sphere it hits (see k_shade, ray64)
+#endif
 #ifndef RT_SPHERE_RANK32
 #define RT_SPHERE_RANK32 2   // scenes with triangles: spheres are ranked by an f32 test, k_shade forms the distance in f64 (1: those in BVH leaves only; 0: f64 discriminants)
 #endif
@@ -1569,7 +1572,11 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
                 // (a hit on a sphere does not read the carried words: its hit point and normal -- a square root, a division -- mix every
                 // bit of the ray anew, so a ray whose f32 origin and direction get random low bits there is statistically the
                 // reference's; 16 bytes less to read for nine rays in ten of C5.  RT_SPHERE_E = 1 reads them there too.)
-                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT) && (flat || RT_SPHERE_E);
+                // (... unless the ray STARTS on that sphere -- the inside of a glass ball: |o - c|^2 - r^2 is then a difference of equal numbers,
+                // zero to an ulp of f64 in the reference, and what an f32 origin leaves of it decides, for the grazing rays that circle
+                // inside the ball, where they come down again: a glass sphere beside a mesh was 5.5 % too bright, tools/soak_objects.py seed 7052)
+                const bool own_sphere = RT_SPHERE_OWN && !flat && (src & ~(SRC_E_BIT | SRC_D_BIT | SRC_SELF_BIT)) == code;
+                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT) && (flat || RT_SPHERE_E || own_sphere);
                 uint4 E = make_uint4(0u, 0u, 0u, 0u);
                 if (carried) E = ld_stream(&qi.e[my]);
                 if (PRIMARY) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
