@@ -177,10 +177,7 @@ __device__ __forceinline__ bool slot_to_pixel(const DevScene& sc, const PassPara
 #define RT_PRIMARY_REFORDER 1
 #endif
 #ifndef RT_SPHERE_E
-#define RT_SPHERE_E 0
-#endif
-#ifndef RT_SPHERE_OWN
-#define RT_SPHERE_OWN 1   // ... except by a ray that starts on the sphere it hits (see k_shade, ray64)
+#define RT_SPHERE_E 1   // a hit on a sphere reads the ray's carried f64 origin like a hit on a triangle or a plane (see k_shade, ray64)
 #endif
 #ifndef RT_SPHERE_RANK32
 #define RT_SPHERE_RANK32 2   // scenes with triangles: spheres are ranked by an f32 test, k_shade forms the distance in f64 (1: those in BVH leaves only; 0: f64 discriminants)
@@ -1569,14 +1566,12 @@ __global__ __launch_bounds__(SHADE_THREADS, TRIS ? RT_SHADE_MINWAVES_TRIS : RT_S
             uint32_t sw = 0;
             auto ray64 = [&](d3& o64, bool flat) {   // flat: the hit is on a triangle or a plane
                 dh = pcg_hash(rng ^ 0x68E31DA4u);          // dither bits: a stream of their own, rng is not advanced
-                // (a hit on a sphere does not read the carried words: its hit point and normal -- a square root, a division -- mix every
-                // bit of the ray anew, so a ray whose f32 origin and direction get random low bits there is statistically the
-                // reference's; 16 bytes less to read for nine rays in ten of C5.  RT_SPHERE_E = 1 reads them there too.)
-                // (... unless the ray STARTS on that sphere -- the inside of a glass ball: |o - c|^2 - r^2 is then a difference of equal numbers,
-                // zero to an ulp of f64 in the reference, and what an f32 origin leaves of it decides, for the grazing rays that circle
-                // inside the ball, where they come down again: a glass sphere beside a mesh was 5.5 % too bright, tools/soak_objects.py seed 7052)
-                const bool own_sphere = RT_SPHERE_OWN && !flat && (src & ~(SRC_E_BIT | SRC_D_BIT | SRC_SELF_BIT)) == code;
-                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT) && (flat || RT_SPHERE_E || own_sphere);
+                // (A hit on a sphere reads the carried words too.  Leaving them out there -- RT_SPHERE_E = 0: its hit point and normal, a square
+                // root and a division, mix every bit of the ray anew, 16 bytes less to read for nine rays in ten of C5, -1.2 % -- passed 3,000
+                // soak scenes and failed two of the next 1,400 by 5 %: a ray INSIDE a glass ball starts on the sphere it hits, where
+                // |o - c|^2 - r^2 is zero to an ulp of f64 in the reference (tools/soak_objects.py seed 7052), and a ray that comes off a flat
+                // glass face onto a mirror ball and back carries the face's exact coordinates with it (seed 8309).)
+                const bool carried = !PRIMARY && src < SRC_SPECIAL && (src & SRC_E_BIT) && (flat || RT_SPHERE_E);
                 uint4 E = make_uint4(0u, 0u, 0u, 0u);
                 if (carried) E = ld_stream(&qi.e[my]);
                 if (PRIMARY) o64 = mkd(sc.eye64[0], sc.eye64[1], sc.eye64[2]);
