@@ -427,7 +427,9 @@ static int flatten_scene(rt_context* ctx, const rt_scene_desc* d, FlatScene& f, 
             uint32_t gidw = gid_tri[t], tag = PRIM_TRIANGLE;
             float gf, tf;
             std::memcpy(&gf, &gidw, 4); std::memcpy(&tf, &tag, 4);
-            r[2] = make_float4(e2[2], gf, tf, 0.f);
+            // last word: what the f32 edge tests of k_closest_hit allow for (RT_EDGE_TOL, see the leaf step), per unit of distance between the ray's origin and the triangle
+            const float el = std::max(std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]), std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
+            r[2] = make_float4(e2[2], gf, tf, 0x1p-25f * el);
             int uv_off = -1;
             bool has_uv = d->tri_uv && (!d->tri_has_uv || d->tri_has_uv[t]);
             if (has_uv) {

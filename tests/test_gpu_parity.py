@@ -65,6 +65,14 @@ def check_hits(got, want, allow_id_mismatch=0):
     return int(id_bad.sum()), float(rel_t.max()), float(nerr.max())
 
 
+def rays_through_a_mesh(got, want):
+    """Rays that hit a triangle in both worlds but at distances more than 1e-3 apart: the device's ray has passed between two
+    triangles of a closed mesh (or has been caught by one it misses) -- the cracks that f32 edge tests leave (k_closest_hit's
+    margin, RT_EDGE_TOL, closes them)."""
+    both = (got["triangle_id"] >= 0) & (want["triangle_id"] >= 0) & (got["triangle_id"] != want["triangle_id"])
+    return int((both & (np.abs(got["t"].astype(np.float64) - want["t"]) > 1e-3 * np.abs(want["t"]))).sum())
+
+
 def oracle_camera_dirs(osc, dx, dy, crop=None):
     """camera.rs:62-67 + raytrace.rs:32-37 in numpy f64 from the oracle's camera: unit direction per pixel."""
     cam = osc.camera()
@@ -698,10 +706,11 @@ def test_full_size_c5_hits_image_and_properties(ctx):
     got, want = hits_pair(ctx, osc, own_camera_id_slack=64)
     on_mesh = want["triangle_id"] >= 0
     assert on_mesh.sum() > 20000 and (want["object_id"] >= 0).mean() > 0.5
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=int(1e-4 * on_mesh.sum()))     # see test_full_size_c4_hits_and_image
+    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8)     # see test_full_size_c4_hits_and_image (measured: 4)
+    assert rays_through_a_mesh(got, want) == 0
     print("C5 1920x1080, all %d primary rays: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e"
           % (got["t"].size, bad, on_mesh.sum(), rt_, rn))
-    PARITY["primary_hits_c5_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
+    PARITY["primary_hits_c5_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad, rays_through_the_mesh=0, max_rel_t=rt_, max_rel_normal=rn)
     rows, cols = np.nonzero(on_mesh)
     r0, c0 = int(np.median(rows)), int(np.median(cols))
     edge_r = int(rows.max()) - 8                                        # lower silhouette of the torus against the ground
@@ -745,15 +754,28 @@ def test_full_size_c4_hits_and_image(ctx):
     assert (sc["width"], sc["height"]) == (3840, 2160)
     ctx.upload(rt.Scene.from_objects(sc["width"], sc["height"], sc["background"], sc["camera"], sc["objects"]))
     osc = O.OracleScene.from_dict(scenegen.to_oracle_dict(sc), accel=True)
-    got, want = hits_pair(ctx, osc, crop=(960, 2880, 540, 1620), own_camera_id_slack=512)   # 2M rays over ~1M triangle edges
+    # BASELINE.json asks for bit-exact ids on scenes/cube.  On the 1M-triangle mesh a ray that passes within f32 rounding of a
+    # shared edge (f32 vertices and Moeller-Trumbore on the device, f64 Cramer in the reference) used to land on the neighbouring
+    # triangle (42 of these 2 M rays) or between the two, on the far side of the tube (74: tools/id_mismatch_probe.py); since the
+    # edge tests of the primary rays have a margin and k_shade / rt_primary_hits decide such a pair in f64 (RT_EDGE_TOL) the ids are
+    # the oracle's (measured: 0, and 1 at the second offset).  A ray through a vertex, where more than two triangles tie, can still differ: bounded at 8.
+    first = None
+    for dx, dy in ((0.0, 0.0), (0.37, 0.71)):            # 2 x 2M rays over ~1M triangle edges
+        got, want = hits_pair(ctx, osc, dx, dy, crop=(960, 2880, 540, 1620), own_camera_id_slack=512 if first is None else None)
+        on_mesh = want["triangle_id"] >= 0
+        assert on_mesh.mean() > 0.5                                      # the torus fills the middle of the frame
+        bad, rt_, rn = check_hits(got, want, allow_id_mismatch=8)
+        assert rays_through_a_mesh(got, want) == 0
+        print("C4 3840x2160, middle 1920x1080 at sub-pixel offset (%.2f, %.2f): %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e"
+              % (dx, dy, bad, on_mesh.sum(), rt_, rn))
+        if first is None:
+            first = (got, want)
+            PARITY["primary_hits_c4_4k_middle_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad,
+                                                             rays_through_the_mesh=0, max_rel_t=rt_, max_rel_normal=rn)
+        else:
+            PARITY["primary_hits_c4_4k_middle_1080p"]["id_mismatches_at_offset_0.37_0.71"] = bad
+    got, want = first
     on_mesh = want["triangle_id"] >= 0
-    assert on_mesh.mean() > 0.5                                          # the torus fills the middle of the frame
-    # BASELINE.json asks for bit-exact ids on scenes/cube; on the 1M-triangle mesh a ray that passes within f32 rounding of
-    # a shared edge (f32 vertices and Moeller-Trumbore on the device, f64 Cramer in the reference) can land on the
-    # neighbouring triangle: the count is reported and bounded at 1 in 10,000 rays on the mesh
-    bad, rt_, rn = check_hits(got, want, allow_id_mismatch=int(1e-4 * on_mesh.sum()))
-    print("C4 3840x2160, middle 1920x1080: %d id mismatches (%d rays on the mesh), max rel t %.2e, normal %.2e" % (bad, on_mesh.sum(), rt_, rn))
-    PARITY["primary_hits_c4_4k_middle_1080p"] = dict(rays=got["t"].size, rays_on_mesh=int(on_mesh.sum()), id_mismatches=bad, max_rel_t=rt_, max_rel_normal=rn)
     check_hits(*hits_pair(ctx, osc, crop=(0, 400, 0, 2160), own_camera_id_slack=16), allow_id_mismatch=4)
     rows, cols = np.nonzero(on_mesh)
     r0, c0 = 540 + int(np.median(rows)), 960 + int(np.median(cols))
